@@ -1,0 +1,159 @@
+// affinity.hip - row L2 normalisation and the patch-feature affinity W = relu(F F^T), exact fp32 on MFMA.
+//
+// Replaces (reference, torch ops on the GPU followed by an N^2 device->host copy):
+//   extract/extract.py:148      feats = F.normalize(feats, p=2, dim=-1)
+//   extract/extract.py:191-193  W_feat = feats @ feats.T ; W_feat = W_feat * (W_feat > 0)
+//   extract/extract.py:194      W_feat / W_feat.max()   -> dropped: (D-W)v = lambda D v is scale invariant
+//   extract/extract.py:195      .cpu().numpy()          -> eliminated: W never leaves HBM
+//
+// Gram kernel: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise an fmaf chain, no TF32-style
+// truncation - gfx950 has none).  Roofline: 2*N^2*D flop against 157.3 TF/s fp32-MFMA; arithmetic
+// intensity D/2 flop/B >> the fp32 ridge (~20), so this kernel is MFMA-bound, not HBM-bound.
+// Tiling: 256 threads = 4 waves (2x2), block tile 128x128, each wave 64x64 = 2x2 MFMA tiles (64
+// accumulator registers); F panels [128 rows x 32 floats] staged through LDS with a 4-float row skew
+// so that ds_read_b128 fragment reads are bank-conflict free (row stride 36 words: 16 rows cover the 16
+// four-bank slots exactly once).
+//
+// MFMA operand maps (cdna_hip_programming.md §3): A: lane l holds A[i=l&31][k=l>>5]; B: B[k=l>>5][j=l&31];
+// D: register r of lane l is D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].  The k index is a dummy: lane half hh
+// feeds feature columns d0+4*hh+s to MFMA number s for both operands.
+#include "common.h"
+
+namespace dss {
+
+// ------------------------------------------------------------------------------------------------
+// y = x / max(||x||, eps) per row; one wave per row.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* xr = x + row * D;
+    float* yr = y + row * D;
+    float ss = 0.f;
+    if ((D & 3) == 0) {
+      for (int c = lane; c < (D >> 2); c += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) ss += xr[c] * xr[c];
+    }
+    const float denom = fmaxf(sqrtf(wave_sum(ss)), eps);
+    if ((D & 3) == 0) {
+      for (int c = lane; c < (D >> 2); c += 64) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+        v[0] /= denom; v[1] /= denom; v[2] /= denom; v[3] /= denom;
+        *reinterpret_cast<f32x4*>(yr + 4 * c) = v;
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) yr[c] = xr[c] / denom;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static constexpr int GB = 128;  // block tile (rows and cols)
+static constexpr int GK = 32;   // feature columns per LDS stage
+static constexpr int GLD = GK + 4;
+
+__global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict__ feats, float* __restrict__ W,
+                                                        int N, int D, int ldw, int relu) {
+  __shared__ __attribute__((aligned(16))) float As[GB][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[GB][GLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int I0 = blockIdx.y * GB, J0 = blockIdx.x * GB;
+  const float* F = feats + (long)blockIdx.z * N * D;
+  float* Wb = W + (long)blockIdx.z * N * ldw;
+
+  // which of this wave's four 32x32 sub-tiles intersect the matrix (wave-uniform)
+  const int ri0 = I0 + wr * 64, cj0 = J0 + wc * 64;
+  const bool act_r0 = ri0 < N, act_r1 = ri0 + 32 < N;
+  const bool act_c0 = cj0 < ldw, act_c1 = cj0 + 32 < ldw;
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  // staging map: 8 threads cover one 128-byte row segment; 32 rows per pass, 4 passes per panel
+  const int srow = tid >> 3, scol = (tid & 7) * 4;
+  for (int d0 = 0; d0 < D; d0 += GK) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      int ga = I0 + r; ga = ga < N ? ga : N - 1;  // clamp: rows past N are computed and discarded
+      int gb = J0 + r; gb = gb < N ? gb : N - 1;
+      *reinterpret_cast<f32x4*>(&As[r][scol]) = *reinterpret_cast<const f32x4*>(F + (long)ga * D + d0 + scol);
+      *reinterpret_cast<f32x4*>(&Bs[r][scol]) = *reinterpret_cast<const f32x4*>(F + (long)gb * D + d0 + scol);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK / 8; ++kk) {
+      const int c = 8 * kk + 4 * hh;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[wr * 64 + li][c]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[wr * 64 + 32 + li][c]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[wc * 64 + li][c]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[wc * 64 + 32 + li][c]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (act_r0 && act_c0) acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc00, 0, 0, 0);
+        if (act_r0 && act_c1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc01, 0, 0, 0);
+        if (act_r1 && act_c0) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc10, 0, 0, 0);
+        if (act_r1 && act_c1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc11, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: relu, zero the pad columns [N, ldw), coalesced 128-byte row segments per half-wave
+  auto store_tile = [&](const f32x16& acc, int rbase, int cbase) {
+    const int col = cbase + li;
+    if (col >= ldw) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row < N) {
+        float v = acc[r];
+        if (relu) v = fmaxf(v, 0.f);
+        if (col >= N) v = 0.f;
+        Wb[(long)row * ldw + col] = v;
+      }
+    }
+  };
+  if (act_r0 && act_c0) store_tile(acc00, ri0, cj0);
+  if (act_r0 && act_c1) store_tile(acc01, ri0, cj0 + 32);
+  if (act_r1 && act_c0) store_tile(acc10, ri0 + 32, cj0);
+  if (act_r1 && act_c1) store_tile(acc11, ri0 + 32, cj0 + 32);
+}
+
+}  // namespace dss
+
+extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream) {
+  DSS_REQUIRE(x && y, "dss_normalize_rows: null pointer");
+  DSS_REQUIRE(rows > 0 && D > 0, "dss_normalize_rows: bad shape rows=%d D=%d", rows, D);
+  int blocks = dss::ceil_div(rows, 4);
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(dss::normalize_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+                     D, eps);
+  DSS_CHECK_LAUNCH("normalize_rows");
+  return DSS_OK;
+}
+
+extern "C" int dss_affinity_ld(int N) { return N > 0 ? dss::round_up(N, 64) : 0; }
+
+extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
+                            void* stream) {
+  DSS_REQUIRE(feats && W, "dss_affinity: null pointer");
+  DSS_REQUIRE(B > 0 && N > 0 && D > 0, "dss_affinity: bad shape B=%d N=%d D=%d", B, N, D);
+  DSS_REQUIRE(D % dss::GK == 0, "dss_affinity: feature dim must be a multiple of %d (got %d)", dss::GK, D);
+  DSS_REQUIRE(B <= 65535, "dss_affinity: B must be <= 65535");
+  const int ldw = dss_affinity_ld(N);
+  const int nb = dss::ceil_div(ldw, dss::GB);
+  hipLaunchKernelGGL(dss::gram_relu_kernel, dim3(nb, dss::ceil_div(N, dss::GB), B), dim3(256), 0,
+                     (hipStream_t)stream, feats, W, N, D, ldw, threshold_at_zero ? 1 : 0);
+  DSS_CHECK_LAUNCH("gram_relu");
+  return DSS_OK;
+}

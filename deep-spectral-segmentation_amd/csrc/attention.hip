@@ -1,0 +1,234 @@
+// attention.hip - fused multi-head self-attention for the DINO ViT blocks (head dim 64), gfx950 MFMA.
+//
+// Replaces DINO's Attention.forward after the qkv Linear (reached from
+// extract/extract.py:94):   attn = softmax((q @ k^T) * scale) ; x = (attn @ v).transpose(1,2).reshape(B,T,C)
+// The [h, T, T] score matrix is never materialised (flash-style online softmax).
+//
+// Two kernels:
+//  1. attn_pack: qkv [B,T,3,h,64] -> Q [B,h,Tp,64], K [B,h,Tp,64], V^T [B,h,64,Tp]  (Tp = T rounded up to
+//     64, zero padded).  V is transposed through LDS because the P.V contraction runs over keys, and an
+//     MFMA operand wants its contraction index contiguous per lane.  Inside every 16-key group V^T's
+//     keys are stored in the order the softmax registers hold them (see KEY ORDER) so one 16-byte load
+//     is one MFMA operand.
+//  2. attn_fwd: one wave = 32 query rows; per 32-key block
+//        S^T[key][q]  = mfma_32x32x16( K-fragment , Q-fragment )      (4 MFMAs, contraction over dh=64)
+//        online softmax down each lane's own query column (16 registers + one lane^32 exchange)
+//        O^T[dh][q]  += mfma_32x32x16( V^T-fragment , P^T-fragment )  (4 MFMAs, contraction over 32 keys)
+//     Computing the TRANSPOSED score tile makes the softmax reduction lane-local and lets the fp32
+//     probabilities be packed straight into the B operand of the second MFMA - no LDS round trip.
+//
+// MFMA layouts used (v_mfma_f32_32x32x16_{f16,bf16}; cdna_hip_programming.md §3):
+//   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + e], e = 0..7   (8 halves = 16 B)
+//   B operand: lane l holds B[k = 8*(l>>5) + e][j = l&31]
+//   C/D      : lane l, register r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+// Only the (i, j) maps matter for correctness: the k index is summed, so any bijection of k is valid as
+// long as A and B use the same one.
+//
+// KEY ORDER.  After the first MFMA lane l (half hh = l>>5) holds, for its query, keys
+//   key(r) = (r&3) + 8*(r>>2) + 4*hh,  r = 0..15  of the 32-key block.  Registers 8t..8t+7 (t = 0,1) form
+// the B operand of P.V MFMA number t, i.e. operand slot (hh, e) carries key 16t + 8*(e>>2) + 4*hh + (e&3).
+// V^T therefore stores, at position 16t + 8*hh + e of each 32-key block, exactly that key.
+#include "common.h"
+
+namespace dss {
+
+static constexpr int DH = 64;  // head dim of every DINO ViT
+
+__host__ __device__ inline int attn_tp(int T) { return (T + 63) / 64 * 64; }
+
+// position p (0..15) inside a 16-key group -> key offset inside the group
+__device__ __forceinline__ int vt_key_of_pos(int p) {
+  const int hh = p >> 3, e = p & 7;
+  return 8 * (e >> 2) + 4 * hh + (e & 3);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_pack_kernel(const T* __restrict__ qkv, T* __restrict__ Qp,
+                                                        T* __restrict__ Kp, T* __restrict__ Vt, int Tn,
+                                                        int Tp, int heads) {
+  typedef typename vec8<T>::type V8;
+  __shared__ __attribute__((aligned(16))) T vtile[64][DH + 8];  // +8 halves: 16-B row skew
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * 64;
+  const int head = blockIdx.y;
+  const int b = blockIdx.z;
+  const int row = tid >> 2;       // token inside the tile
+  const int ch = (tid & 3) * 16;  // 16 halves per thread
+  const int tok = t0 + row;
+  const long src_row = ((long)b * Tn + tok) * 3 * heads * DH + (long)head * DH + ch;
+  const long dst_row = (((long)b * heads + head) * Tp + tok) * DH + ch;
+  V8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (T)0.f;
+  V8 q0 = z, q1 = z, k0 = z, k1 = z, v0 = z, v1 = z;
+  if (tok < Tn) {
+    const T* s = qkv + src_row;
+    q0 = *reinterpret_cast<const V8*>(s);
+    q1 = *reinterpret_cast<const V8*>(s + 8);
+    k0 = *reinterpret_cast<const V8*>(s + (long)heads * DH);
+    k1 = *reinterpret_cast<const V8*>(s + (long)heads * DH + 8);
+    v0 = *reinterpret_cast<const V8*>(s + 2L * heads * DH);
+    v1 = *reinterpret_cast<const V8*>(s + 2L * heads * DH + 8);
+  }
+  *reinterpret_cast<V8*>(Qp + dst_row) = q0;
+  *reinterpret_cast<V8*>(Qp + dst_row + 8) = q1;
+  *reinterpret_cast<V8*>(Kp + dst_row) = k0;
+  *reinterpret_cast<V8*>(Kp + dst_row + 8) = k1;
+  *reinterpret_cast<V8*>(&vtile[row][ch]) = v0;
+  *reinterpret_cast<V8*>(&vtile[row][ch + 8]) = v1;
+  __syncthreads();
+  // transposed write: thread -> (dh = tid>>2, 16 consecutive POSITIONS of the 64-key tile)
+  const int dh = tid >> 2;
+  const int p0 = (tid & 3) * 16;
+  V8 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    o0[i] = vtile[p0 + vt_key_of_pos(i)][dh];
+    o1[i] = vtile[p0 + vt_key_of_pos(8 + i)][dh];
+  }
+  T* d = Vt + (((long)b * heads + head) * DH + dh) * Tp + t0 + p0;
+  *reinterpret_cast<V8*>(d) = o0;
+  *reinterpret_cast<V8*>(d + 8) = o1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Qp, const T* __restrict__ Kp,
+                                                       const T* __restrict__ Vt, T* __restrict__ out, int Tn,
+                                                       int Tp, int heads, float scale_log2) {
+  typedef typename vec8<T>::type V8;
+  typedef typename vec4<T>::type V4;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= Tn) return;  // whole wave out of range (no block-level barrier in this kernel)
+  const long bh = (long)b * heads + head;
+  const T* Qb = Qp + bh * Tp * DH;
+  const T* Kb = Kp + bh * Tp * DH;
+  const T* Vb = Vt + bh * DH * Tp;
+
+  V8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *reinterpret_cast<const V8*>(Qb + (long)(q0 + li) * DH + 16 * s + 8 * hh);
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -1.0e30f, lsum = 0.f;
+
+  const int nkb = (Tn + 31) / 32;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int key0 = kb * 32;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const V8 kf = *reinterpret_cast<const V8*>(Kb + (long)(key0 + li) * DH + 16 * sl + 8 * hh);
+      s = mfma32x32x16(kf, qf[sl], s);
+    }
+    const bool tail = key0 + 32 > Tn;
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = s[r] * scale_log2;
+      if (tail) {
+        const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= Tn) v = -INFINITY;
+      }
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      rs += s[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    lsum = lsum * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    V8 pb0, pb1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pb0[e] = from_f32<T>(s[e]);
+      pb1[e] = from_f32<T>(s[8 + e]);
+    }
+    const T* vrow0 = Vb + (long)li * Tp + key0 + 8 * hh;
+    const T* vrow1 = Vb + (long)(32 + li) * Tp + key0 + 8 * hh;
+    const V8 v00 = *reinterpret_cast<const V8*>(vrow0);
+    const V8 v01 = *reinterpret_cast<const V8*>(vrow0 + 16);
+    const V8 v10 = *reinterpret_cast<const V8*>(vrow1);
+    const V8 v11 = *reinterpret_cast<const V8*>(vrow1 + 16);
+    o0 = mfma32x32x16(v00, pb0, o0);
+    o0 = mfma32x32x16(v01, pb1, o0);
+    o1 = mfma32x32x16(v10, pb0, o1);
+    o1 = mfma32x32x16(v11, pb1, o1);
+  }
+
+  const int q = q0 + li;
+  if (q < Tn) {
+    const float inv = 1.0f / lsum;
+    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      V4 a, c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = from_f32<T>(o0[4 * g + i] * inv);
+        c[i] = from_f32<T>(o1[4 * g + i] * inv);
+      }
+      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
+      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = c;
+    }
+  }
+}
+
+template <class T>
+static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, void* ws,
+                             hipStream_t s) {
+  const int Tp = attn_tp(Tn);
+  const size_t panel = (size_t)B * heads * Tp * DH;
+  T* Qp = (T*)ws;
+  T* Kp = Qp + panel;
+  T* Vt = Kp + panel;
+  hipLaunchKernelGGL((attn_pack_kernel<T>), dim3(Tp / 64, heads, B), dim3(256), 0, s, (const T*)qkv, Qp, Kp,
+                     Vt, Tn, Tp, heads);
+  const float scale_log2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(ceil_div(Tn, 128), heads, B), dim3(256), 0, s, Qp, Kp, Vt,
+                     (T*)out, Tn, Tp, heads, scale_log2);
+}
+
+}  // namespace dss
+
+extern "C" size_t dss_attention_workspace_bytes(int B, int T, int heads) {
+  if (B <= 0 || T <= 0 || heads <= 0) return 0;
+  return (size_t)3 * B * heads * dss::attn_tp(T) * dss::DH * 2;
+}
+
+extern "C" int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale,
+                                 int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  DSS_REQUIRE(qkv && out && workspace, "dss_attention_fwd: null pointer");
+  DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
+  DSS_REQUIRE(B <= 65535 && heads <= 65535, "dss_attention_fwd: B and heads must be <= 65535");
+  if (workspace_bytes < dss_attention_workspace_bytes(B, T, heads))
+    return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes,
+                     dss_attention_workspace_bytes(B, T, heads));
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s); break;
+    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s); break;
+    default: return dss::fail(DSS_ERR_BAD_ARG, "dss_attention_fwd: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
+  }
+  DSS_CHECK_LAUNCH("attention");
+  return DSS_OK;
+}

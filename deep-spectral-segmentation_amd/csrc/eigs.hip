@@ -1,0 +1,88 @@
+// eigs.hip - kernel wrappers + C ABI for the Laplacian eigen stage (algorithm: eigs_core.h) and the
+// stand-alone sign rule.
+#include "common.h"
+#include "eigs_core.h"
+
+namespace dss {
+
+static constexpr int EIGS_THREADS = 1024;  // 16 waves: enough 16-byte loads in flight to stream W per CU
+
+__global__ __launch_bounds__(EIGS_THREADS) void laplacian_eigs_kernel(const float* __restrict__ W, EigsParams P,
+                                                                      float* gws, size_t gws_stride,
+                                                                      float* eigenvalues, float* eigenvectors,
+                                                                      int32_t* info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const size_t b = blockIdx.x;
+  eigs_one_image(W + b * (size_t)P.N * P.ld, P, gws + b * gws_stride, lds, eigenvalues + b * P.K,
+                 eigenvectors + b * (size_t)P.K * P.N, info + b);
+}
+
+// extract/extract.py:238-240 on its own: one workgroup per vector.
+__global__ __launch_bounds__(256) void sign_rule_kernel(float* v, int N) {
+  __shared__ int cnt;
+  float* row = v + (size_t)blockIdx.x * N;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int pos = 0;
+  for (int e = threadIdx.x; e < N; e += blockDim.x) pos += row[e] > 0.f ? 1 : 0;
+  pos = (int)(wave_sum((float)pos) + 0.5f);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, pos);
+  __syncthreads();
+  const int c = cnt;
+  if (2 * c > N && c < N)
+    for (int e = threadIdx.x; e < N; e += blockDim.x) row[e] = 0.f - row[e];
+}
+
+static int resolve_ncv(int N, int K, int ncv) {
+  if (ncv <= 0) ncv = 2 * K + 10 > 20 ? 2 * K + 10 : 20;
+  if (ncv > EIGS_MAX_NCV) ncv = EIGS_MAX_NCV;
+  if (ncv > N) ncv = N;
+  return ncv;
+}
+
+}  // namespace dss
+
+extern "C" size_t dss_eigs_workspace_bytes(int B, int N, int K, int ncv) {
+  if (B <= 0 || N <= 0 || K <= 0) return 0;
+  ncv = dss::resolve_ncv(N, K, ncv);
+  return (size_t)B * dss::eigs_ws_floats_per_image(dss_affinity_ld(N), ncv) * sizeof(float);
+}
+
+extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
+                                  int32_t* info, int ncv, float tol, int max_restarts, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  DSS_REQUIRE(W && eigenvalues && eigenvectors && info && workspace, "dss_laplacian_eigs: null pointer");
+  DSS_REQUIRE(B > 0 && N > 1 && K > 0, "dss_laplacian_eigs: bad shape B=%d N=%d K=%d", B, N, K);
+  DSS_REQUIRE(K < N, "dss_laplacian_eigs: need K < N (K=%d, N=%d)", K, N);
+  ncv = dss::resolve_ncv(N, K, ncv);
+  DSS_REQUIRE(ncv >= K + 2 || ncv == N,
+              "dss_laplacian_eigs: Krylov dimension %d too small for K=%d (max %d)", ncv, K, dss::EIGS_MAX_NCV);
+  const int ld = dss_affinity_ld(N);
+  const size_t per_img = dss::eigs_ws_floats_per_image(ld, ncv);
+  if (workspace_bytes < (size_t)B * per_img * sizeof(float))
+    return dss::fail(DSS_ERR_WORKSPACE, "dss_laplacian_eigs: workspace %zu < %zu bytes", workspace_bytes,
+                     (size_t)B * per_img * sizeof(float));
+  dss::EigsParams P;
+  P.N = N; P.ld = ld; P.K = K; P.ncv = ncv;
+  P.keep = (ncv + K) / 2;  // tuned on tests/golden with the host emulation (tests/host_emul)
+  P.max_restarts = max_restarts > 0 ? max_restarts : 60;
+  P.tol = tol > 0.f ? tol : 2e-6f;
+  const dss::EigsLds L = dss::eigs_lds_layout(ld, ncv);
+  DSS_REQUIRE(L.total <= 160 * 1024, "dss_laplacian_eigs: N=%d needs %zu B of LDS (> 160 KiB)", N, L.total);
+  hipError_t e = hipFuncSetAttribute((const void*)dss::laplacian_eigs_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+  if (e != hipSuccess)
+    return dss::fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
+  hipLaunchKernelGGL(dss::laplacian_eigs_kernel, dim3(B), dim3(dss::EIGS_THREADS), L.total, (hipStream_t)stream,
+                     W, P, (float*)workspace, per_img, eigenvalues, eigenvectors, info);
+  DSS_CHECK_LAUNCH("laplacian_eigs");
+  return DSS_OK;
+}
+
+extern "C" int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream) {
+  DSS_REQUIRE(eigenvectors, "dss_sign_rule: null pointer");
+  DSS_REQUIRE(rows > 0 && N > 0, "dss_sign_rule: bad shape rows=%d N=%d", rows, N);
+  hipLaunchKernelGGL(dss::sign_rule_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, eigenvectors, N);
+  DSS_CHECK_LAUNCH("sign_rule");
+  return DSS_OK;
+}

@@ -1,0 +1,249 @@
+"""``extract_features`` / ``extract_eigs`` - MI355X-native drop-in for the two hot commands of the
+reference's ``extract/extract.py`` (:21-116 and :119-280).  Same command names, flag names, defaults,
+skip-if-exists behaviour and ``.pth`` schemas, so the reference's downstream
+scripts (object-localization/main.py:254-272, extract.py:283-426) consume the outputs unchanged.
+
+    python deep-spectral-segmentation_amd/extract.py extract_features \
+        --images_list ./data/VOC2012/lists/images.txt --images_root ./data/VOC2012/images \
+        --output_dir ./data/VOC2012/features/dino_vits16 --model_name dino_vits16 --batch_size 1
+    python deep-spectral-segmentation_amd/extract.py extract_eigs \
+        --images_root ./data/VOC2012/images --features_dir ./data/VOC2012/features/dino_vits16 \
+        --which_matrix laplacian --output_dir ./data/VOC2012/eigs/laplacian --K 5
+
+Under ``python -m torch.distributed.run --nproc-per-node N`` every rank takes the items
+``i % world_size == rank`` of the sorted work list (one process per GPU, no collective on the data path).
+
+Scope: ``which_matrix`` in {'laplacian', 'matting_laplacian'} with ``image_color_lambda == 0`` and
+``lapnorm=True`` - the ``extract_eigs`` defaults and the README recipes.  Other branches of the reference
+(``affinity*``, colour affinities, feature upsampling, ``lapnorm=False``) raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import ast
+import inspect
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from functools import partial
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+if __package__ in (None, ""):  # executed as a script: make the package importable as `dss_amd`
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import dss_amd  # noqa: F401
+    from dss_amd import extract_utils as utils
+    from dss_amd import spectral
+    from dss_amd.distributed import rank_world, local_device
+else:
+    from . import extract_utils as utils
+    from . import spectral
+    from .distributed import rank_world, local_device
+
+_DTYPES = {"float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+           "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
+def _feature_dict(k: torch.Tensor, index: int, file: str, model_name: str, patch_size: int,
+                  shape: Tuple[int, int, int, int]) -> dict:
+    """The reference's feature-file schema (extract/extract.py:98,104-110)."""
+    return {"k": k.detach().cpu(), "indices": torch.tensor(index), "file": file, "id": Path(file).stem,
+            "model_name": model_name, "patch_size": patch_size, "shape": tuple(int(s) for s in shape)}
+
+
+def extract_features(images_list: str, images_root: Optional[str], model_name: str, batch_size: int,
+                     output_dir: str, which_block: int = -1, weights: Optional[str] = None,
+                     dtype: str = "float16", synthetic_weights: Optional[int] = None):
+    """Extract features from a list of images (see module docstring).  ``batch_size`` is the maximum
+    number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
+    whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76)."""
+    utils.make_output_dir(output_dir)
+    model_name = model_name.lower()
+    if not ("dino" in model_name or "mocov3" in model_name):
+        raise ValueError(model_name)
+    rank, world = rank_world()
+    device = local_device()
+    model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
+                                              weights=weights, synthetic_seed=synthetic_weights)
+
+    filenames = Path(images_list).read_text().splitlines()
+    dataset = utils.ImagesDataset(filenames=filenames, images_root=images_root, transform=None)
+    print(f"Dataset size: {len(dataset)=}")
+    todo = []
+    for i in range(rank, len(dataset), world):
+        out = Path(output_dir) / f"{Path(dataset.filenames[i]).stem}.pth"
+        if out.is_file():
+            print(f"Skipping existing file {str(out)}")
+            continue
+        todo.append((i, out))
+
+    def flush(batch: List[Tuple[int, Path, torch.Tensor, str]]):
+        if not batch:
+            return
+        imgs = torch.stack([b[2] for b in batch]).to(device, non_blocking=True)
+        k = model.extract_k(imgs, which_block=which_block).cpu()
+        h, w = imgs.shape[1], imgs.shape[2]
+        for j, (idx, out, _, file) in enumerate(batch):
+            torch.save(_feature_dict(k[j:j + 1].clone(), idx, file, model_name, patch_size, (1, 3, h, w)),
+                       str(out))
+        batch.clear()
+
+    batch: List[Tuple[int, Path, torch.Tensor, str]] = []
+    with ThreadPoolExecutor(max_workers=8) as pool:  # the reference's 8 loader workers (extract.py:60)
+        for (idx, out), (img, file, _) in zip(todo, pool.map(lambda t: dataset[t[0]], todo)):
+            if batch and (tuple(batch[0][2].shape) != tuple(img.shape) or len(batch) >= max(1, int(batch_size))):
+                flush(batch)
+            batch.append((idx, out, img, file))
+        flush(batch)
+    if world > 1:
+        torch.distributed.barrier()
+    print(f"Saved features to {output_dir}")
+
+
+def _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, patch_size):
+    if which_matrix not in ("laplacian", "matting_laplacian"):
+        raise NotImplementedError(f"which_matrix={which_matrix!r}: only the (matting_)laplacian path is built")
+    if not lapnorm:
+        raise NotImplementedError("lapnorm=False (un-normalised Laplacian) is not built")
+    if image_color_lambda > 0:
+        raise NotImplementedError("image_color_lambda > 0 (KNN / random-walk colour affinities) is not built")
+    if image_downsample_factor is not None and image_downsample_factor != patch_size:
+        raise NotImplementedError("feature upsampling (image_downsample_factor != patch size) is not built")
+
+
+def _load_features(features_file: str, which_features: str) -> Tuple[dict, torch.Tensor]:
+    data_dict = torch.load(features_file, map_location="cpu", weights_only=False)
+    feats = data_dict[which_features].squeeze()
+    if feats.dim() != 2:
+        raise ValueError(f"{features_file}: expected [1, N, D] features, got {tuple(data_dict[which_features].shape)}")
+    return data_dict, feats.to(torch.float32)
+
+
+def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: bool, threshold_at_zero: bool,
+                   device: torch.device):
+    feats = torch.stack([f for _, f in items]).to(device, non_blocking=True)
+    ev, vec, _ = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
+                                                       threshold_at_zero=threshold_at_zero)
+    ev, vec = ev.cpu(), vec.cpu()
+    for j, (output_file, _) in enumerate(items):
+        # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32
+        torch.save({"eigenvalues": ev[j].clone(), "eigenvectors": vec[j].clone()}, output_file)
+
+
+def _extract_eig(inp: Tuple[int, str], K: int, images_root: str, output_dir: str,
+                 which_matrix: str = "laplacian", which_features: str = "k", normalize: bool = True,
+                 lapnorm: bool = True, which_color_matrix: str = "knn", threshold_at_zero: bool = True,
+                 image_downsample_factor: Optional[int] = None, image_color_lambda: float = 10):
+    """One feature file -> one eigen file (same signature as the reference's ``_extract_eig``; note its
+    ``image_color_lambda`` default of 10 is only reachable by calling this function directly)."""
+    index, features_file = inp
+    data_dict, feats = _load_features(str(features_file), which_features)
+    image_id = data_dict["file"][:-4]
+    output_file = str(Path(output_dir) / f"{image_id}.pth")
+    if Path(output_file).is_file():
+        print(f"Skipping existing file {str(output_file)}")
+        return
+    _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, data_dict["patch_size"])
+    utils.get_image_sizes(data_dict)  # keeps the reference's B == 1 assertion
+    _run_eig_batch([(output_file, feats)], K, normalize, threshold_at_zero, local_device())
+
+
+def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_matrix: str = "laplacian",
+                 which_color_matrix: str = "knn", which_features: str = "k", normalize: bool = True,
+                 threshold_at_zero: bool = True, lapnorm: bool = True, K: int = 20,
+                 image_downsample_factor: Optional[int] = None, image_color_lambda: float = 0.0,
+                 multiprocessing: int = 0, batch_size: int = 64):
+    """Extracts eigenvalues/eigenvectors from features (see module docstring).  ``multiprocessing`` is
+    accepted for CLI compatibility and ignored; ``batch_size`` same-shape images share one kernel launch."""
+    utils.make_output_dir(output_dir)
+    kwargs = dict(K=K, which_matrix=which_matrix, which_features=which_features,
+                  which_color_matrix=which_color_matrix, normalize=normalize, threshold_at_zero=threshold_at_zero,
+                  images_root=images_root, output_dir=output_dir, image_downsample_factor=image_downsample_factor,
+                  image_color_lambda=image_color_lambda, lapnorm=lapnorm)
+    print(kwargs)
+    if multiprocessing:
+        print("[dss] multiprocessing flag ignored: images are batched on the GPU")
+    rank, world = rank_world()
+    device = local_device()
+    files = sorted(Path(features_dir).iterdir())
+    mine = files[rank::world]
+
+    def load(f):
+        data_dict, feats = _load_features(str(f), which_features)
+        return data_dict, feats
+
+    pending: Dict[Tuple[int, int], List[Tuple[str, torch.Tensor]]] = {}
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        for data_dict, feats in pool.map(load, mine):
+            image_id = data_dict["file"][:-4]
+            output_file = str(Path(output_dir) / f"{image_id}.pth")
+            if Path(output_file).is_file():
+                print(f"Skipping existing file {str(output_file)}")
+                continue
+            _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
+                               data_dict["patch_size"])
+            utils.get_image_sizes(data_dict)
+            key = tuple(feats.shape)
+            pending.setdefault(key, []).append((output_file, feats))
+            if len(pending[key]) >= max(1, int(batch_size)):
+                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device)
+    for key in list(pending):
+        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device)
+    if world > 1:
+        torch.distributed.barrier()
+
+
+# ------------------------------------------------------------------------------------------ CLI
+COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs)
+
+
+def _literal(s: str):
+    try:
+        return ast.literal_eval(s)
+    except (ValueError, SyntaxError):
+        return s
+
+
+def parse_cli(argv: List[str]):
+    """python-fire style: ``<command> --flag value`` or ``--flag=value``; values are Python literals when
+    they parse as one (True / None / 5 / 0.5), strings otherwise; a bare ``--flag`` means True."""
+    if not argv or argv[0] not in COMMANDS:
+        raise SystemExit(f"usage: extract.py {{{'|'.join(COMMANDS)}}} --flag value ...")
+    fn = COMMANDS[argv[0]]
+    params = inspect.signature(fn).parameters
+    kwargs, i = {}, 1
+    while i < len(argv):
+        a = argv[i]
+        if not a.startswith("--"):
+            raise SystemExit(f"unexpected positional argument {a!r}")
+        if "=" in a:
+            key, val = a[2:].split("=", 1)
+            i += 1
+        elif i + 1 < len(argv) and not argv[i + 1].startswith("--"):
+            key, val = a[2:], argv[i + 1]
+            i += 2
+        else:
+            key, val = a[2:], "True"
+            i += 1
+        key = key.replace("-", "_")
+        if key == "yes":
+            os.environ["DSS_ASSUME_YES"] = "1"
+            continue
+        if key not in params:
+            raise SystemExit(f"{argv[0]}: unknown flag --{key} (known: {', '.join(params)})")
+        kwargs[key] = _literal(val)
+    missing = [n for n, p in params.items() if p.default is inspect.Parameter.empty and n not in kwargs]
+    if missing:
+        raise SystemExit(f"{argv[0]}: missing required flags: {', '.join('--' + m for m in missing)}")
+    return fn, kwargs
+
+
+def main(argv: Optional[List[str]] = None):
+    torch.set_grad_enabled(False)  # extract/extract.py:838
+    fn, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    fn(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+"""ctypes binding of ``libdss_hip.so`` (C ABI declared in ``include/dss_hip.h``).
+
+The product path has NO fallback: if the library is missing or a call fails, ``HipLibraryError`` is
+raised.  Tensors are passed as raw device pointers (``tensor.data_ptr()``), the stream as the
+``hipStream_t`` of ``torch.cuda.current_stream()`` - PyTorch is only the allocator/stream provider.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libdss_hip.so"
+
+DSS_F32, DSS_F16, DSS_BF16 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: DSS_F32, torch.float16: DSS_F16, torch.bfloat16: DSS_BF16}
+
+# every symbol include/dss_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "dss_abi_version": (c_int, []),
+    "dss_last_error": (c_char_p, []),
+    "dss_target_arch": (c_char_p, []),
+    "dss_preprocess_chw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dss_preprocess_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_float, c_void_p]),
+    "dss_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dss_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
+    "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dss_affinity_ld": (c_int, [c_int]),
+    "dss_affinity": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dss_laplacian_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                   c_int, c_void_p, c_size_t, c_void_p]),
+    "dss_sign_rule": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    """libdss_hip.so is missing, failed to load, or one of its entry points returned an error."""
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load_library(path: Optional[Path] = None) -> ctypes.CDLL:
+    """Load the library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise HipLibraryError(
+            f"{p} not found: build it with `python deep-spectral-segmentation_amd/build.py` "
+            "(hipcc, gfx950).  There is no CPU/PyTorch fallback for the kernels.")
+    try:
+        lib = ctypes.CDLL(str(p))
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise HipLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{p} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().dss_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str) -> int:
+    if not t.is_cuda:
+        raise HipLibraryError(f"{what}: tensor must live on the GPU (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{what}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dt]
+    except KeyError:
+        raise HipLibraryError(f"unsupported dtype {dt}") from None
+
+
+# --------------------------------------------------------------------------------------- image transform
+def preprocess_chw(img_u8: torch.Tensor) -> torch.Tensor:
+    """u8 ``[B, H, W, 3]`` -> f32 ``[B, 3, H, W]`` (extract_utils.py:55-56)."""
+    b, h, w, c = img_u8.shape
+    assert c == 3 and img_u8.dtype == torch.uint8
+    out = torch.empty((b, 3, h, w), dtype=torch.float32, device=img_u8.device)
+    _check(load_library().dss_preprocess_chw(_dev(img_u8, "img"), _dev(out, "out"), b, h, w, _stream()),
+           "dss_preprocess_chw")
+    return out
+
+
+def preprocess_patchify(img_u8: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
+    """u8 ``[B, H, W, 3]`` -> ``[B, (H//P)*(W//P), 3*P*P]`` transformed, cropped, im2col'ed."""
+    b, h, w, c = img_u8.shape
+    assert c == 3 and img_u8.dtype == torch.uint8
+    out = torch.empty((b, (h // patch) * (w // patch), 3 * patch * patch), dtype=dtype, device=img_u8.device)
+    _check(load_library().dss_preprocess_patchify(_dev(img_u8, "img"), _dev(out, "out"), b, h, w, patch,
+                                                  dtype_code(dtype), _stream()), "dss_preprocess_patchify")
+    return out
+
+
+# --------------------------------------------------------------------------------------- ViT kernels
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype,
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``LN(x (+ residual))`` over the last dim; with ``residual`` the sum is written back into ``x``."""
+    assert x.dtype == torch.float32
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rp, rc = (0, 0) if residual is None else (_dev(residual, "residual"), dtype_code(residual.dtype))
+    if residual is not None:
+        assert residual.shape == x.shape
+    _check(load_library().dss_layernorm_fwd(_dev(x, "x"), rp, rc, _dev(gamma, "gamma"), _dev(beta, "beta"),
+                                            _dev(out, "out"), dtype_code(out.dtype), rows, d, float(eps),
+                                            _stream()), "dss_layernorm_fwd")
+    return out
+
+
+def attention_workspace_bytes(b: int, t: int, heads: int) -> int:
+    return int(load_library().dss_attention_workspace_bytes(b, t, heads))
+
+
+def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``qkv`` ``[B, T, 3*heads*64]`` (fp16/bf16) -> ``[B, T, heads*64]``."""
+    b, t, c3 = qkv.shape
+    assert c3 == 3 * heads * 64, "head dim must be 64"
+    need = attention_workspace_bytes(b, t, heads)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    if out is None:
+        out = torch.empty((b, t, heads * 64), dtype=qkv.dtype, device=qkv.device)
+    _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), b, t, heads, float(scale),
+                                            dtype_code(qkv.dtype), _dev(workspace, "workspace"),
+                                            workspace.numel() * workspace.element_size(), _stream()),
+           "dss_attention_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------------------- spectral stage
+def normalize_rows(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    assert x.dtype == torch.float32
+    d = x.shape[-1]
+    out = torch.empty_like(x)
+    _check(load_library().dss_normalize_rows(_dev(x, "x"), _dev(out, "out"), x.numel() // d, d, float(eps),
+                                             _stream()), "dss_normalize_rows")
+    return out
+
+
+def affinity_ld(n: int) -> int:
+    return int(load_library().dss_affinity_ld(n))
+
+
+def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tensor:
+    """f32 ``[B, N, D]`` -> f32 ``[B, N, ld]`` with ``W[b, i, j] = relu(<f_i, f_j>)`` for j < N, 0 beyond."""
+    assert feats.dtype == torch.float32 and feats.dim() == 3
+    b, n, d = feats.shape
+    w = torch.empty((b, n, affinity_ld(n)), dtype=torch.float32, device=feats.device)
+    _check(load_library().dss_affinity(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(threshold_at_zero),
+                                       _stream()), "dss_affinity")
+    return w
+
+
+def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0.0, max_restarts: int = 0,
+                   workspace: Optional[torch.Tensor] = None):
+    """``W`` ``[B, N, ld]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]`` int32)."""
+    assert w.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == n and w.shape[2] == affinity_ld(n)
+    b = w.shape[0]
+    lib = load_library()
+    need = int(lib.dss_eigs_workspace_bytes(b, n, k, ncv))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=w.device)
+    evals = torch.empty((b, k), dtype=torch.float32, device=w.device)
+    evecs = torch.empty((b, k, n), dtype=torch.float32, device=w.device)
+    info = torch.zeros((b,), dtype=torch.int32, device=w.device)
+    _check(lib.dss_laplacian_eigs(_dev(w, "W"), b, n, k, _dev(evals, "evals"), _dev(evecs, "evecs"),
+                                  _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
+                                  workspace.numel() * workspace.element_size(), _stream()),
+           "dss_laplacian_eigs")
+    return evals, evecs, info
+
+
+def sign_rule_(vecs: torch.Tensor) -> torch.Tensor:
+    assert vecs.dtype == torch.float32
+    n = vecs.shape[-1]
+    _check(load_library().dss_sign_rule(_dev(vecs, "vecs"), vecs.numel() // n, n, _stream()), "dss_sign_rule")
+    return vecs

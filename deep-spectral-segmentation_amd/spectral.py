@@ -1,0 +1,70 @@
+"""Per-image spectral step on the GPU: features -> affinity -> Laplacian eigenpairs.
+
+Host-side orchestration of the HIP pipeline that replaces the body of the reference's ``_extract_eig``
+for ``which_matrix in ('laplacian', 'matting_laplacian')`` with ``image_color_lambda == 0``
+(extract/extract.py:146-148, 175-195, 215-240).  Everything stays in HBM: there is no N x N
+device->host copy and no scipy.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import hip
+
+
+class EigsNotConverged(RuntimeError):
+    pass
+
+
+@torch.no_grad()
+def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
+                                 threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
+                                 max_restarts: int = 0, max_bytes: int = 24 << 30,
+                                 strict: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
+    ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
+
+    * eigenvalues ascending (``lambda_0 ~ 0``), eigenvectors D-orthonormal, sign rule applied - the
+      conventions of the reference's ``.pth`` schema.
+    * images are processed in chunks whose affinity matrices fit in ``max_bytes`` of HBM.
+    * ``strict``: raise ``EigsNotConverged`` if any image exhausted its restart budget (the reference
+      would have raised ``ArpackNoConvergence`` into a bare ``except``)."""
+    if feats.dim() == 2:
+        feats = feats[None]
+    assert feats.dim() == 3 and feats.dtype == torch.float32
+    b, n, d = feats.shape
+    if not K < n:
+        raise ValueError(f"need K < N (K={K}, N={n})")
+    ld = hip.affinity_ld(n)
+    per_image = n * ld * 4 + 2 * 66 * ld * 4
+    chunk = max(1, min(b, max_bytes // per_image))
+    evals, evecs, infos = [], [], []
+    for s in range(0, b, chunk):
+        f = feats[s:s + chunk].contiguous()
+        if normalize:
+            f = hip.normalize_rows(f)
+        w = hip.affinity(f, threshold_at_zero)
+        ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts)
+        evals.append(ev), evecs.append(vec), infos.append(info)
+        del w
+    ev, vec, info = torch.cat(evals), torch.cat(evecs), torch.cat(infos)
+    if strict:
+        bad = (info <= 0).nonzero().flatten().tolist()
+        if bad:
+            raise EigsNotConverged(f"Lanczos did not converge for images {bad[:8]} (info={info[bad[:8]].tolist()})")
+    return ev, vec, info
+
+
+def group_by_shape(shapes: List[Tuple[int, ...]], max_batch: int) -> List[List[int]]:
+    """Indices grouped into batches of identical shape (order of first appearance preserved inside a
+    batch; batches ordered by their first member)."""
+    buckets, order = {}, []
+    for i, s in enumerate(shapes):
+        key = tuple(s)
+        if key not in buckets or len(buckets[key][-1]) >= max_batch:
+            buckets.setdefault(key, []).append([])
+            order.append(buckets[key][-1])
+        buckets[key][-1].append(i)
+    return order

@@ -1,0 +1,171 @@
+"""DINO ViT forward for the feature stage, MI355X-native.
+
+What the reference runs (extract/extract.py:51-53,94-98): ``model.get_intermediate_layers(images)``
+on the torch.hub DINO ViT with a forward hook on ``blocks[which_block].attn.qkv``; only the K third of
+that one Linear's output is kept.  This module computes exactly that tensor and nothing after it:
+
+* blocks ``0 .. which_block-1`` run in full; block ``which_block`` runs ``norm1`` and the K rows of its
+  qkv Linear only (its attention/proj/MLP and the final norm never influence the hooked tensor;
+  SURVEY.md §0.4) - identical output, ~8 % fewer FLOPs for the default ``which_block=-1``.
+* LayerNorm (+ the preceding residual add) and attention are the hand-written HIP kernels of
+  ``libdss_hip.so``; Linear layers are PyTorch-ROCm GEMMs (hipBLASLt) with fp16/bf16 operands and fp32
+  accumulation.  The residual stream, LayerNorm statistics, softmax statistics and the final K
+  projection stay fp32.
+* the image transform + crop + im2col is one HIP kernel, so the patch embedding is a plain GEMM.
+
+``state_dict`` keys are those of facebookresearch/dino, so a real DINO checkpoint
+loads unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .synthetic import VIT_CONFIGS
+
+LN_EPS = 1e-6
+
+
+def interpolate_pos_encoding(pos_embed: torch.Tensor, patch: int, h: int, w: int) -> torch.Tensor:
+    """DINO's ``interpolate_pos_encoding`` for an ``h x w`` (pixels, multiples of ``patch``) input:
+    bicubic resize of the ``sqrt(N0) x sqrt(N0)`` grid with the published ``+0.1`` scale-factor trick.
+    Evaluated once per input shape on the CPU in fp32 (cached by the caller)."""
+    pos_embed = pos_embed.detach().float().cpu()
+    n0 = pos_embed.shape[1] - 1
+    hp, wp = h // patch, w // patch
+    if hp * wp == n0 and h == w:
+        return pos_embed.clone()
+    dim = pos_embed.shape[-1]
+    side = int(math.sqrt(n0))
+    grid = pos_embed[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=((hp + 0.1) / side, (wp + 0.1) / side), mode="bicubic")
+    if (grid.shape[-2], grid.shape[-1]) != (hp, wp):
+        raise RuntimeError(f"pos-embed interpolation produced {tuple(grid.shape[-2:])}, wanted {(hp, wp)}")
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((pos_embed[:, :1], grid), dim=1)
+
+
+class DinoViT:
+    """Inference-only DINO ViT holding its weights on one GPU."""
+
+    def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
+                 dtype: torch.dtype = torch.float16):
+        name = model_name.lower()
+        if name not in VIT_CONFIGS:
+            raise ValueError(f"Cannot get model: {model_name}")
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+        self.model_name = name
+        self.embed_dim, self.depth, self.num_heads, self.patch_size = VIT_CONFIGS[name]
+        self.device, self.dtype = torch.device(device), dtype
+        d = self.embed_dim
+        sd = state_dict
+        need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+        for i in range(self.depth):
+            for s in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                      "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                      "mlp.fc2.weight", "mlp.fc2.bias"):
+                need.append(f"blocks.{i}.{s}")
+        missing = [k for k in need if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict is missing {len(missing)} DINO ViT keys, e.g. {missing[:3]}")
+
+        def lp(t):  # GEMM operand
+            return t.detach().to(self.device, dtype).contiguous()
+
+        def f32(t):
+            return t.detach().to(self.device, torch.float32).contiguous()
+
+        self.cls_token = sd["cls_token"].detach().float().cpu()
+        self.pos_embed = sd["pos_embed"].detach().float().cpu()
+        self.pe_w = lp(sd["patch_embed.proj.weight"].reshape(d, -1))  # [D, 3*P*P], (c, py, px) inner order
+        self.pe_b = lp(sd["patch_embed.proj.bias"])
+        self.blocks = []
+        for i in range(self.depth):
+            p = f"blocks.{i}."
+            self.blocks.append(dict(
+                n1w=f32(sd[p + "norm1.weight"]), n1b=f32(sd[p + "norm1.bias"]),
+                qkv_w=lp(sd[p + "attn.qkv.weight"]), qkv_b=lp(sd[p + "attn.qkv.bias"]),
+                k_w32=f32(sd[p + "attn.qkv.weight"][d:2 * d]), k_b32=f32(sd[p + "attn.qkv.bias"][d:2 * d]),
+                proj_w=lp(sd[p + "attn.proj.weight"]), proj_b=lp(sd[p + "attn.proj.bias"]),
+                n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
+                fc1_w=lp(sd[p + "mlp.fc1.weight"]), fc1_b=lp(sd[p + "mlp.fc1.bias"]),
+                fc2_w=lp(sd[p + "mlp.fc2.weight"]), fc2_b=lp(sd[p + "mlp.fc2.bias"]),
+            ))
+        self.scale = 64 ** -0.5
+        assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
+        self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._attn_ws: Optional[torch.Tensor] = None
+        hip.load_library()  # fail now, not mid-run, if the kernels are missing
+
+    # ------------------------------------------------------------------------------------------
+    def _pos(self, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(cls_token + pos[0]) as ``[D]`` and pos[1:] as ``[N, D]`` on the device, fp32."""
+        key = (h, w)
+        if key not in self._pos_cache:
+            pe = interpolate_pos_encoding(self.pos_embed, self.patch_size, h, w)
+            cls_row = (self.cls_token[0, 0] + pe[0, 0]).to(self.device)
+            self._pos_cache[key] = (cls_row.contiguous(), pe[0, 1:].to(self.device).contiguous())
+        return self._pos_cache[key]
+
+    def _attn_workspace(self, b: int, t: int) -> torch.Tensor:
+        need = hip.attention_workspace_bytes(b, t, self.num_heads)
+        if self._attn_ws is None or self._attn_ws.numel() < need:
+            self._attn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._attn_ws
+
+    @torch.no_grad()
+    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1) -> torch.Tensor:
+        """``img_u8``: u8 ``[B, H, W, 3]`` RGB on the GPU (uncropped).  Returns the hooked K features
+        ``[B, N, D]`` fp32, ``N = (H//P)*(W//P)``, rows in row-major patch order, CLS removed."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+        b, h, w, _ = img_u8.shape
+        p, d, heads = self.patch_size, self.embed_dim, self.num_heads
+        hp, wp = h // p, w // p
+        if hp == 0 or wp == 0:
+            raise ValueError(f"image {h}x{w} is smaller than one {p}x{p} patch")
+        n, t = hp * wp, hp * wp + 1
+        wb = which_block if which_block >= 0 else self.depth + which_block
+        if not 0 <= wb < self.depth:
+            raise IndexError(f"which_block={which_block} out of range for depth {self.depth}")
+
+        patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
+        tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
+        cls_row, pos = self._pos(hp * p, wp * p)
+        x = torch.empty((b, t, d), dtype=torch.float32, device=self.device)  # fp32 residual stream
+        x[:, 0] = cls_row
+        torch.add(tok, pos, out=x[:, 1:])
+        ws = self._attn_workspace(b, t)
+
+        pending = None  # branch output not yet added to the residual stream (fused into the next LN)
+        for i in range(wb):
+            blk = self.blocks[i]
+            hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
+            qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
+            o = hip.attention(qkv, heads, self.scale, workspace=ws)
+            pending = F.linear(o, blk["proj_w"], blk["proj_b"])
+            hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
+            f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
+            pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
+        blk = self.blocks[wb]
+        h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)
+        k = F.linear(h32, blk["k_w32"], blk["k_b32"])  # fp32 GEMM: the features handed to the eigen stage
+        return k[:, 1:, :].contiguous()
+
+
+def load_dino_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """Read a DINO checkpoint (the ``*_pretrain.pth`` files torch.hub would have downloaded, or a
+    full-checkpoint dict with a ``teacher``/``student`` entry)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    for key in ("teacher", "student", "state_dict", "model"):
+        if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+            sd = sd[key]
+    out = {}
+    for k, v in sd.items():
+        k = k.replace("module.", "").replace("backbone.", "")
+        out[k] = v
+    return out

@@ -1,0 +1,113 @@
+/* dss_hip.h - C ABI of libdss_hip.so: the MI355X (gfx950) kernels behind the
+ * deep-spectral-segmentation `extract.py` hot path (extract_features -> extract_eigs).
+ *
+ * The reference has no FFI/plugin seam of its own (pure Python): its seam is
+ * the two CLI commands, their Python signatures and two .pth schemas.  This header is the
+ * native boundary underneath that seam.  Every entry point cites the reference lines whose
+ * arithmetic it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no C++/torch types.  All pointers are DEVICE pointers
+ *     (HBM) owned by the caller unless stated; row-major; fp32 unless a dtype argument says so.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Every call
+ *     only ENQUEUES work on that stream and returns; nothing synchronises, nothing allocates.
+ *   - Return value: DSS_OK (0) or a negative DSS_ERR_* code; dss_last_error() gives the message
+ *     (thread-local).  Functions are re-entrant; there is no global mutable state.
+ *   - Half-precision dtypes: DSS_F16 (IEEE binary16) / DSS_BF16; DSS_F32 where noted.
+ */
+#ifndef DSS_HIP_H
+#define DSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSS_ABI_VERSION 1
+
+enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
+
+enum {
+  DSS_OK = 0,
+  DSS_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, unsupported shape/dtype */
+  DSS_ERR_HIP = -2,          /* a HIP runtime call / kernel launch failed                */
+  DSS_ERR_WORKSPACE = -3,    /* workspace too small                                      */
+  DSS_ERR_NO_CONVERGENCE = -4 /* reported per image through `info`, never as return code  */
+};
+
+/* ---- library ------------------------------------------------------------------------- */
+int dss_abi_version(void);
+const char* dss_last_error(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* dss_target_arch(void);
+
+/* ---- a2/a3/a5: image transform ---------------------------------------------------------
+ * extract/extract_utils.py:55-56  ToTensor (u8 HWC -> f32 CHW, /255) + Normalize(ImageNet)
+ * extract/extract.py:82-88        crop to (H//P*P, W//P*P), top-left
+ * img_u8: [B, H, W, 3] RGB.  out_chw: [B, 3, H, W] f32 - the uncropped transformed image,
+ * bit-exact to the reference transform (IEEE division, same operation order). */
+int dss_preprocess_chw(const uint8_t* img_u8, float* out_chw, int B, int H, int W, void* stream);
+/* Fused transform + crop + im2col for the patch-embedding GEMM:
+ * out: [B, (H/P)*(W/P), 3*P*P] in `out_dtype`, inner index (c, py, px) = Conv2d weight order;
+ * patch index n = (y/P)*(W/P) + (x/P)  (row-major, the reference's patch order). */
+int dss_preprocess_patchify(const uint8_t* img_u8, void* out, int B, int H, int W, int P,
+                            int out_dtype, void* stream);
+
+/* ---- a6': LayerNorm (DINO blocks' norm1/norm2, eps 1e-6) ------------
+ * y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta, statistics in fp32 (biased var).
+ * x: [rows, D] f32.  y: [rows, D] in out_dtype.  D % 4 == 0, D <= 2048.
+ * If `residual` != NULL (dtype `res_dtype`, [rows, D]) the kernel first does x += residual
+ * IN PLACE (the block's `x = x + attn(...)` / `x = x + mlp(...)`) and normalises the sum. */
+int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, const float* gamma,
+                      const float* beta, void* y, int out_dtype, int rows, int D, float eps,
+                      void* stream);
+
+/* ---- a6'': multi-head self-attention (DINO Attention.forward, heads of 64) ----------------
+ * qkv: [B, T, 3, heads, 64] in `dtype` (the qkv Linear's output, untouched);
+ * out: [B, T, heads*64] in `dtype`  = softmax(q k^T * scale) v, heads re-interleaved as the
+ * reference's `.transpose(1, 2).reshape(B, T, C)`.  fp32 accumulation and softmax statistics.
+ * workspace: dss_attention_workspace_bytes(B, T, heads) bytes (packed Q/K/V^T panels). */
+size_t dss_attention_workspace_bytes(int B, int T, int heads);
+int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a10: row L2 normalisation -------------------------------------------------------------
+ * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */
+int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream);
+
+/* ---- a12: patch-feature affinity -------------------------------------------------------------
+ * extract/extract.py:191-194  W = F F^T ; W = W * (W > 0)   (exact fp32 MFMA, fmaf-chain numerics).
+ * `W / W.max()` (:194) is NOT applied: the generalized problem (D-W)v = lambda D v is invariant
+ * under W -> cW; eigenvalues and eigenvectors are unchanged.
+ * feats: [B, N, D] f32 (already normalised if wanted).  W: [B, N, ldw] f32, ldw = dss_affinity_ld(N)
+ * (row stride padded to 64 floats; pad columns are written as 0). */
+int dss_affinity_ld(int N);
+int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
+                 void* stream);
+
+/* ---- a13-a15: degree, normalised Laplacian, K smallest generalized eigenpairs, sign rule -------
+ * extract/extract_utils.py:207-220  d = W 1 ; d[d < 1e-12] = 1
+ * extract/extract.py:227            eigsh(D - W, k=K, sigma=0, which='LM', M=D)
+ * extract/extract.py:235-240        eigenvectors.T (f32 [K, N]) ; sign rule
+ * Solved as the K LARGEST eigenpairs (mu, u) of S = D^-1/2 W D^-1/2 by thick-restart Lanczos
+ * with full reorthogonalisation (one workgroup per image; W streamed once per Lanczos step);
+ * lambda = 1 - mu ascending, v = D^-1/2 u  (so v^T D v = 1, the reference's normalisation).
+ * W: [B, N, ldw] f32 symmetric non-negative.  eigenvalues: [B, K] f32.  eigenvectors: [B, K, N] f32.
+ * info: [B] int32 - number of W passes (>0) if converged, -(passes) if the restart budget ran out
+ * (outputs then hold the best available Ritz pairs).
+ * ncv: Krylov dimension (0 = default max(2K+10, 20), capped at 64); tol: Ritz residual tolerance
+ * relative to max(|mu|, 1e-3) (0 = default 2e-6); max_restarts (0 = default 60). */
+size_t dss_eigs_workspace_bytes(int B, int N, int K, int ncv);
+int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
+                       int32_t* info, int ncv, float tol, int max_restarts,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a15: sign rule alone (extract/extract.py:238-240), in place on [rows, N] ----------------- */
+int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSS_HIP_H */

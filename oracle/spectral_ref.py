@@ -1,0 +1,114 @@
+"""ORACLE (test infrastructure, never shipped): CPU restatement of the reference's eigen
+stage, ``_extract_eig`` with ``which_matrix='laplacian'`` (the ``extract_eigs`` default).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product path never does; it fails loudly without its HIP library.
+
+Follows, line by line:
+  extract/extract.py:146-148   feats = k.squeeze(); F.normalize(p=2, dim=-1)
+  extract/extract.py:191-195   W = F F^T ; W *= (W > 0) ; W /= W.max() ; to numpy
+  extract/extract.py:215-222   W_color = 0 ; W_comb = W ; D = get_diagonal(W_comb).todense()
+  extract/extract_utils.py:207-220  d = row_sum(W) ; d[d < 1e-12] = 1 ; diags(d)
+  extract/extract.py:227       eigsh(D - W, k=K, sigma=0, which='LM', M=D)
+  extract/extract.py:235       eigenvectors.T -> float32 [K, N]
+  extract/extract.py:238-240   sign rule
+Third-party arithmetic reached by those lines and absent from /root/reference:
+  scipy.sparse.linalg.eigsh (ARPACK ssaupd/sseupd + LAPACK getrf/getrs; scipy 1.15.3 here,
+  unpinned in requirements.txt:6) - called, not restated;
+  pymatting.util.util.row_sum (unpinned, requirements.txt:10) - restated as ``W @ ones``
+  (its published definition: ``A.dot(np.ones(A.shape[1], A.dtype))``).
+
+PARITY PIN: the reference has no tests; this restatement is pinned against outputs of the
+reference's own ``_extract_eig`` executed in the build container through inert import
+stubs (oracle/make_golden.py -> tests/golden/eigs_*.npz; checked by tests/test_oracle.py).
+Two oracle calls are not bit-identical (ARPACK start vector) - compare by |cos|.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.sparse.linalg import eigsh
+
+
+def ref_affinity(feats: torch.Tensor, normalize: bool = True, threshold_at_zero: bool = True) -> np.ndarray:
+    """``[N, D]`` f32 -> dense ``[N, N]`` f32 affinity (extract.py:146-148,191-195)."""
+    feats = feats.squeeze().to(torch.float32)
+    if normalize:
+        feats = F.normalize(feats, p=2, dim=-1)
+    w = feats @ feats.T
+    if threshold_at_zero:
+        w = w * (w > 0)
+    w = w / w.max()
+    return w.cpu().numpy()
+
+
+def ref_degree(w: np.ndarray, threshold: float = 1e-12) -> np.ndarray:
+    """extract_utils.py:207-220 (row_sum restated)."""
+    d = w.dot(np.ones(w.shape[1], w.dtype))
+    d[d < threshold] = 1.0
+    return d
+
+
+def ref_sign_rule(eigenvectors: torch.Tensor) -> torch.Tensor:
+    """extract.py:238-240, in place on a ``[K, N]`` tensor."""
+    for k in range(eigenvectors.shape[0]):
+        if 0.5 < torch.mean((eigenvectors[k] > 0).float()).item() < 1.0:
+            eigenvectors[k] = 0 - eigenvectors[k]
+    return eigenvectors
+
+
+def ref_laplacian_eigs(feats: torch.Tensor, K: int, normalize: bool = True,
+                       threshold_at_zero: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Full eigen stage for one image.  Returns (eigenvalues ``[K]``, eigenvectors ``[K, N]`` f32)."""
+    w = ref_affinity(feats, normalize, threshold_at_zero)
+    d = ref_degree(w)
+    dmat = np.diag(d)  # == np.array(scipy.sparse.diags(d).todense())
+    eigenvalues, eigenvectors = eigsh(dmat - w, k=K, sigma=0, which="LM", M=dmat)
+    eigenvalues = torch.from_numpy(eigenvalues)
+    eigenvectors = torch.from_numpy(eigenvectors.T).float()
+    return eigenvalues, ref_sign_rule(eigenvectors)
+
+
+def dense_f64_eigs(feats: np.ndarray, K: int, normalize: bool = True,
+                   threshold_at_zero: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """Independent fp64 dense solve of the same generalized problem (noise-floor probe,
+    SURVEY.md Appendix C): returns ascending eigenvalues ``[K]`` and D-orthonormal vectors ``[K, N]``."""
+    import scipy.linalg
+
+    x = np.asarray(feats, np.float64)
+    if normalize:
+        x = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+    w = x @ x.T
+    if threshold_at_zero:
+        w = w * (w > 0)
+    d = w.sum(1)
+    d[d < 1e-12] = 1.0
+    lam, vec = scipy.linalg.eigh(np.diag(d) - w, np.diag(d), subset_by_index=[0, K - 1])
+    return lam, vec.T
+
+
+def cos_err(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """``1 - |cos|`` per row of two ``[K, N]`` arrays (the BASELINE.json parity metric)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    num = np.abs((a * b).sum(1))
+    den = np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1)
+    return 1.0 - num / np.maximum(den, 1e-300)
+
+
+def subspace_err(a: np.ndarray, b: np.ndarray, d: np.ndarray | None = None) -> float:
+    """``1 - cos(largest principal angle)`` between the row spaces of ``a`` and ``b`` (used when
+    adjacent eigenvalues are closer than the per-vector comparison can resolve).  With ``d`` the
+    angle is measured in the D inner product the eigenvectors are orthonormal in."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if d is not None:
+        s = np.sqrt(np.asarray(d, np.float64))
+        a, b = a * s, b * s
+    qa, _ = np.linalg.qr(a.T)
+    qb, _ = np.linalg.qr(b.T)
+    sv = np.linalg.svd(qa.T @ qb, compute_uv=False)
+    return float(1.0 - sv.min())

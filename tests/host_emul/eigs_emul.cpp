@@ -1,0 +1,32 @@
+// TEST INFRASTRUCTURE ONLY - single-thread host emulation of csrc/eigs_core.h (the block-cooperative
+// Lanczos the GPU kernel runs), built by tests/ with g++ so the restart / Rayleigh-Ritz logic can be
+// checked against tests/golden on a machine without a GPU.  Not part of libdss_hip.so; the product
+// never loads this.
+#define DSS_HOST_EMUL 1
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../deep-spectral-segmentation_amd/csrc/eigs_core.h"
+
+extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int K, float* eigenvalues,
+                                       float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
+                                       int max_restarts) {
+  using namespace dss;
+  if (ncv > EIGS_MAX_NCV) ncv = EIGS_MAX_NCV;
+  if (ncv > N) ncv = N;
+  EigsParams P;
+  P.N = N; P.ld = ld; P.K = K; P.ncv = ncv; P.keep = keep; P.max_restarts = max_restarts; P.tol = tol;
+  const EigsLds L = eigs_lds_layout(ld, ncv);
+  std::vector<unsigned char> lds(L.total + 64);
+  unsigned char* lp = lds.data();
+  lp += (16 - ((uintptr_t)lp & 15)) & 15;
+  std::vector<float> gws(eigs_ws_floats_per_image(ld, ncv));
+  for (int b = 0; b < B; ++b) {
+    memset(lp, 0, L.total);
+    eigs_one_image(W + (size_t)b * N * ld, P, gws.data(), lp, eigenvalues + (size_t)b * K,
+                   eigenvectors + (size_t)b * K * N, info + b);
+  }
+  return 0;
+}

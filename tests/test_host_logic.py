@@ -1,0 +1,122 @@
+"""CPU: host-side logic of the drop-in boundary (no kernels run)."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import dss_amd  # noqa: F401
+from dss_amd import distributed, extract, extract_utils, hip, spectral, synthetic
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    header = (REPO / "include" / "dss_hip.h").read_text()
+    declared = set(re.findall(r"\b(dss_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    lib = hip.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dss_abi_version() == 1 and lib.dss_target_arch() == b"gfx950"
+    assert lib.dss_affinity_ld(900) == 960 and lib.dss_affinity_ld(64) == 64
+    assert lib.dss_eigs_workspace_bytes(1, 900, 5, 0) > 0
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(hip.HipLibraryError):
+        hip.normalize_rows(torch.zeros(4, 8))
+    with pytest.raises(hip.HipLibraryError):
+        hip.load_library(REPO / "does_not_exist.so")
+
+
+def test_product_never_imports_oracle():
+    for f in (REPO / "deep-spectral-segmentation_amd").glob("*.py"):
+        assert "oracle" not in f.read_text().replace("oracle/", ""), f
+
+
+def test_cli_parsing_matches_fire_conventions():
+    fn, kw = extract.parse_cli(["extract_eigs", "--images_root", "r", "--features_dir=f", "--output_dir", "o",
+                                "--K", "5", "--normalize", "False", "--image_downsample_factor=None", "--lapnorm"])
+    assert fn is extract.extract_eigs
+    assert kw == dict(images_root="r", features_dir="f", output_dir="o", K=5, normalize=False,
+                      image_downsample_factor=None, lapnorm=True)
+    with pytest.raises(SystemExit):
+        extract.parse_cli(["extract_eigs", "--images_root", "r"])  # missing required flags
+    with pytest.raises(SystemExit):
+        extract.parse_cli(["extract_features", "--bogus", "1"])
+    import inspect
+    sig = inspect.signature(extract.extract_eigs).parameters
+    assert sig["K"].default == 20 and sig["image_color_lambda"].default == 0.0 and sig["which_matrix"].default == "laplacian"
+    assert inspect.signature(extract._extract_eig).parameters["image_color_lambda"].default == 10
+    first = list(inspect.signature(extract.extract_features).parameters)[:6]
+    assert first == ["images_list", "images_root", "model_name", "batch_size", "output_dir", "which_block"]
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        extract._check_eig_options("affinity", True, 0.0, None, 16)
+    with pytest.raises(NotImplementedError):
+        extract._check_eig_options("laplacian", True, 10.0, None, 16)
+    with pytest.raises(NotImplementedError):
+        extract._check_eig_options("laplacian", False, 0.0, None, 16)
+    extract._check_eig_options("matting_laplacian", True, 0.0, 16, 16)
+
+
+def test_dataset_order_and_image_sizes(tmp_path):
+    from PIL import Image
+
+    for fn, (h, w) in {"b.png": (20, 30), "a.png": (17, 40)}.items():
+        Image.fromarray(synthetic.synthetic_image(1, h, w)).save(tmp_path / fn)
+    ds = extract_utils.ImagesDataset(["b.png", "a.png", "b.png"], images_root=str(tmp_path))
+    assert ds.filenames == ["a.png", "b.png"] and len(ds) == 2
+    img, path, idx = ds[0]
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (17, 40, 3) and path == "a.png" and idx == 0
+    assert np.array_equal(img.numpy(), synthetic.synthetic_image(1, 17, 40))
+    sizes = extract_utils.get_image_sizes({"patch_size": 16, "shape": (1, 3, 375, 500)})
+    assert sizes == (1, 3, 375, 500, 16, 23, 31, 368, 496)
+    with pytest.raises(AssertionError):
+        extract_utils.get_image_sizes({"patch_size": 16, "shape": (2, 3, 32, 32)})
+
+
+def test_feature_schema_roundtrip(tmp_path):
+    d = extract._feature_dict(torch.zeros(1, 6, 8), 3, "x/img_01.jpg", "dino_vits16", 16, (1, 3, 40, 56))
+    torch.save(d, tmp_path / "f.pth")
+    back = torch.load(tmp_path / "f.pth", map_location="cpu", weights_only=True)
+    assert sorted(back) == sorted(["k", "indices", "file", "id", "model_name", "patch_size", "shape"])
+    assert back["k"].dtype == torch.float32 and back["indices"].dim() == 0 and back["indices"].dtype == torch.int64
+    assert back["id"] == "img_01" and back["file"][:-4] == "x/img_01" and back["shape"] == (1, 3, 40, 56)
+
+
+def test_cpu_transform_matches_oracle():
+    from oracle import vit_ref
+
+    img = synthetic.synthetic_image(3, 33, 47)
+    assert torch.equal(extract_utils.get_transform("dino_vits16")(img), vit_ref.ref_preprocess(img))
+
+
+def test_group_by_shape():
+    groups = spectral.group_by_shape([(1, 2), (3, 4), (1, 2), (1, 2), (3, 4)], max_batch=2)
+    assert groups == [[0, 2], [1, 4], [3]]
+
+
+def test_pack_unpack_and_shard():
+    K, N, n = 3, 7, 5
+    ids = torch.tensor([9, 2, 4, 0, 7])
+    val, vec = torch.randn(n, K), torch.randn(n, K, N)
+    i2, v2, e2 = distributed.unpack_results(distributed.pack_results(ids, val, vec), K, N)
+    assert torch.equal(i2, ids) and torch.equal(v2, val) and torch.equal(e2, vec)
+    assert distributed.shard_indices(10, 1, 4) == [1, 5, 9]
+    allidx = sorted(sum((distributed.shard_indices(10, r, 4) for r in range(4)), []))
+    assert allidx == list(range(10))
+    out = distributed.gather_to_root(distributed.pack_results(ids, val, vec), n)
+    assert out[:, -1].tolist() == [0.0, 2.0, 4.0, 7.0, 9.0]
+
+
+def test_synthetic_inputs_are_portable():
+    a = synthetic.synthetic_image(7, 48, 64)
+    assert a.dtype == np.uint8 and a.shape == (48, 64, 3) and int(a.astype(np.int64).sum()) == int(synthetic.synthetic_image(7, 48, 64).astype(np.int64).sum())
+    sd = synthetic.synthetic_state_dict("dino_vitb8", 0)
+    assert sd["pos_embed"].shape == (1, 785, 768) and sd["blocks.11.attn.qkv.weight"].shape == (2304, 768)
+    assert sd["patch_embed.proj.weight"].shape == (768, 3, 8, 8)
