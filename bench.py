@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py - images/sec of the extract hot path (features + eigs) on MI355X, with the kernel roofline
+and a CPU baseline (the oracle, i.e. the reference's numpy/scipy/torch-CPU path) timed beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]          # N=1 directly; N>1 under torch.distributed.run
+
+Workload (BASELINE.json configs[1]): dino_vits16, 480x480 synthetic VOC-shaped images, K=5.
+One STEP = one batch of ``--batch`` images (default 256) already resident in HBM as uint8 HWC:
+transform+crop+im2col -> ViT (HIP LayerNorm/attention, hipBLASLt GEMMs) -> K features -> normalise ->
+affinity -> Lanczos eigenpairs -> [K, N] eigenvectors.  One ``B=1`` result per image, like the reference.
+Multi-GPU: every rank runs the same number of steps on its own images (weak scaling, no collective on the
+data path) and rank 0 gathers all eigenvectors once at the end (inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+import dss_amd  # noqa: E402,F401
+from dss_amd import distributed, hip, pipeline, synthetic  # noqa: E402
+from dss_amd.vit import DinoViT  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA16_PEAK_TF = 2500.0     # dense bf16/fp16 MFMA
+MFMA32_PEAK_TF = 157.3      # fp32 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
+    ap.add_argument("--vit-batch", type=int, default=64, help="images per ViT forward")
+    ap.add_argument("--model", default="dino_vits16")
+    ap.add_argument("--size", type=int, default=480)
+    ap.add_argument("--K", type=int, default=5)
+    ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16"])
+    ap.add_argument("--cpu-images", type=int, default=6, help="images of the same workload timed on the CPU oracle")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images generated per rank")
+    return ap.parse_args()
+
+
+def step(model, imgs, K, vit_batch):
+    ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
+    k = torch.cat(ks) if len(ks) > 1 else ks[0]
+    from dss_amd import spectral
+    return spectral.laplacian_eigs_from_features(k, K, strict=False)
+
+
+def summarize_timers(timers, n_patches, dim, depth_attn):
+    """Average HIP-event duration per launch and the algorithmic work per launch."""
+    out = {}
+    for name, recs in timers.items():
+        ms = [s.elapsed_time(e) for s, e, _ in recs]
+        if not ms:
+            continue
+        tot, avg = float(np.sum(ms)), float(np.mean(ms))
+        entry = {"launches": len(ms), "total_ms": round(tot, 3), "avg_ms": round(avg, 4)}
+        metas = [m for _, _, m in recs]
+        if name == "laplacian_eigs":
+            n = metas[0]["n"]
+            passes = [float(m["info"].abs().sum().item()) for m in metas]
+            byts = np.mean(passes) * 4.0 * n * n     # 4*N^2 algorithmic bytes per pass over W
+            entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                         passes_per_image=float(np.sum(passes) / sum(m["b"] for m in metas)))
+        elif name == "attention":
+            m = metas[0]
+            flops = 4.0 * m["t"] ** 2 * m["heads"] * 64 * m["b"]
+            entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s")
+        elif name == "affinity":
+            m = metas[0]
+            flops = 2.0 * m["n"] ** 2 * m["d"] * m["b"]
+            entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
+        elif name == "layernorm":
+            byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
+            entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        if "achieved" in entry:
+            entry["achieved"] = round(entry["achieved"], 2)
+            entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
+        out[name] = entry
+    return out
+
+
+def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals):
+    """The oracle (CPU restatement of the reference path) on the same synthetic images/weights, all host
+    cores; also yields the eigenvector parity of the GPU results on those images."""
+    from oracle import spectral_ref, vit_ref
+    from tests.util import check_eigs
+
+    ref = vit_ref.build_ref_vit(model_name, sd)
+    cores = torch.get_num_threads()
+    times, worst, ok = [], 0.0, True
+    for i in range(n_images + 1):  # image 0 is the warm-up
+        img = synthetic.synthetic_image(i, size, size)
+        t0 = time.perf_counter()
+        k = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
+        lam, vec = spectral_ref.ref_laplacian_eigs(k, K)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+        ce = spectral_ref.cos_err(gpu_vecs[i].cpu().numpy(), vec.numpy())
+        worst = max(worst, float(ce.max()))
+        try:
+            check_eigs(gpu_vecs[i].cpu().numpy(), gpu_vals[i].cpu().numpy(), vec.numpy(), lam.numpy(), what=f"img{i}")
+        except AssertionError as e:
+            ok = False
+            print(f"[bench] parity failure: {e}", file=sys.stderr)
+    return ({"value": round(len(times) / sum(times), 3), "unit": "images/s", "cores": cores, "kind": "port",
+             "sample": f"{len(times)} of the same {size}x{size} synthetic images, torch-CPU fp32 ViT + "
+                       f"numpy/scipy eigsh (oracle/), 1 warm-up image excluded"},
+            {"max_cos_err_vs_cpu": worst, "within_1e-4_cluster_aware": ok, "images": n_images + 1})
+
+
+def main():
+    a = parse()
+    rank, world = distributed.init_process_group()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = distributed.local_device()
+    dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
+    dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
+    sd = synthetic.synthetic_state_dict(a.model, 0)
+    model = DinoViT(a.model, sd, dev, dtype)
+    n_patches = (a.size // patch) ** 2
+
+    # synthetic images, resident in HBM before the timed region (rank r owns global indices r, r+world, ...)
+    n_distinct = min(a.distinct, a.batch * (a.steps + a.warmup))
+    host = np.stack([synthetic.synthetic_image(rank + world * i, a.size, a.size) for i in range(n_distinct)])
+    pool = torch.from_numpy(host).to(dev)
+
+    def batch_for(s):
+        idx = (torch.arange(a.batch, device=dev) + s * a.batch) % n_distinct
+        return pool[idx]
+
+    for s in range(a.warmup):
+        step(model, batch_for(s), a.K, a.vit_batch)
+    torch.cuda.synchronize()
+
+    hip.TIMERS = {}
+    results = []
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch)
+        results.append((ev, vec, info))
+    ev = torch.cat([r[0] for r in results])
+    vec = torch.cat([r[1] for r in results])
+    ids = torch.arange(ev.shape[0], device=dev) * world + rank
+    gathered = distributed.gather_to_root(distributed.pack_results(ids, ev, vec), ev.shape[0] * world)
+    if gathered is not None:
+        gathered = gathered.cpu()  # D2H of every [K, N] result on rank 0
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    timers, hip.TIMERS = hip.TIMERS, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    info_all = torch.cat([r[2] for r in results])
+    n_unconverged = int((info_all <= 0).sum().item())
+    if rank == 0:
+        kern = summarize_timers(timers, n_patches, dim, depth)
+        dominant = max((k for k in kern if "achieved" in kern[k]), key=lambda k: kern[k]["total_ms"])
+        d = kern[dominant]
+        roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": None}
+        out = {
+            "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
+            "value": round(a.steps * a.batch * world / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.model} {a.size}x{a.size} K={a.K}, {a.batch} images/step/GPU, one B=1 result "
+                                   f"per image (BASELINE.json configs[1])", "images_per_step": a.batch,
+                       "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
+                       "accumulate": "fp32", "eig_dtype": "f32", "parallelism": f"dp{world} round-robin, 1 gather"},
+            "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
+        }
+        if world == 1 and a.cpu_images > 0:
+            first = step(model, pool[: a.cpu_images + 1], a.K, a.vit_batch)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(a.model, sd, a.size, a.K, a.cpu_images, first[1], first[0])
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

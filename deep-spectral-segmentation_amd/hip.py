@@ -47,6 +47,28 @@ class HipLibraryError(RuntimeError):
 
 _lib: Optional[ctypes.CDLL] = None
 
+# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  When
+# ``TIMERS`` is a dict, every wrapper appends (start_event, end_event, meta) to TIMERS[name].
+TIMERS: Optional[dict] = None
+
+
+class _timed:
+    def __init__(self, name: str, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.end.record()
+            TIMERS.setdefault(self.name, []).append((self.start, self.end, self.meta))
+        return False
+
 
 def load_library(path: Optional[Path] = None) -> ctypes.CDLL:
     """Load the library and bind every declared symbol (raises if any is missing)."""
@@ -131,9 +153,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     rp, rc = (0, 0) if residual is None else (_dev(residual, "residual"), dtype_code(residual.dtype))
     if residual is not None:
         assert residual.shape == x.shape
-    _check(load_library().dss_layernorm_fwd(_dev(x, "x"), rp, rc, _dev(gamma, "gamma"), _dev(beta, "beta"),
-                                            _dev(out, "out"), dtype_code(out.dtype), rows, d, float(eps),
-                                            _stream()), "dss_layernorm_fwd")
+    with _timed("layernorm", rows=rows, d=d, res=residual is not None, out_bytes=out.element_size()):
+        _check(load_library().dss_layernorm_fwd(_dev(x, "x"), rp, rc, _dev(gamma, "gamma"), _dev(beta, "beta"),
+                                                _dev(out, "out"), dtype_code(out.dtype), rows, d, float(eps),
+                                                _stream()), "dss_layernorm_fwd")
     return out
 
 
@@ -151,10 +174,11 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[t
         workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
     if out is None:
         out = torch.empty((b, t, heads * 64), dtype=qkv.dtype, device=qkv.device)
-    _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), b, t, heads, float(scale),
-                                            dtype_code(qkv.dtype), _dev(workspace, "workspace"),
-                                            workspace.numel() * workspace.element_size(), _stream()),
-           "dss_attention_fwd")
+    with _timed("attention", b=b, t=t, heads=heads):
+        _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), b, t, heads, float(scale),
+                                                dtype_code(qkv.dtype), _dev(workspace, "workspace"),
+                                                workspace.numel() * workspace.element_size(), _stream()),
+               "dss_attention_fwd")
     return out
 
 
@@ -177,8 +201,9 @@ def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tenso
     assert feats.dtype == torch.float32 and feats.dim() == 3
     b, n, d = feats.shape
     w = torch.empty((b, n, affinity_ld(n)), dtype=torch.float32, device=feats.device)
-    _check(load_library().dss_affinity(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(threshold_at_zero),
-                                       _stream()), "dss_affinity")
+    with _timed("affinity", b=b, n=n, d=d):
+        _check(load_library().dss_affinity(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(threshold_at_zero),
+                                           _stream()), "dss_affinity")
     return w
 
 
@@ -194,10 +219,11 @@ def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0
     evals = torch.empty((b, k), dtype=torch.float32, device=w.device)
     evecs = torch.empty((b, k, n), dtype=torch.float32, device=w.device)
     info = torch.zeros((b,), dtype=torch.int32, device=w.device)
-    _check(lib.dss_laplacian_eigs(_dev(w, "W"), b, n, k, _dev(evals, "evals"), _dev(evecs, "evecs"),
-                                  _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
-                                  workspace.numel() * workspace.element_size(), _stream()),
-           "dss_laplacian_eigs")
+    with _timed("laplacian_eigs", b=b, n=n, k=k, info=info):
+        _check(lib.dss_laplacian_eigs(_dev(w, "W"), b, n, k, _dev(evals, "evals"), _dev(evecs, "evecs"),
+                                      _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
+                                      workspace.numel() * workspace.element_size(), _stream()),
+               "dss_laplacian_eigs")
     return evals, evecs, info
 
 

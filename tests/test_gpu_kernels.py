@@ -1,0 +1,223 @@
+"""GPU (-m gpu): parity of every HIP kernel, called through the C ABI (dss_amd.hip -> libdss_hip.so),
+against the CPU oracle / fp64 references on seeded inputs, plus the reference goldens."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dss_amd  # noqa: F401
+from dss_amd import hip, spectral, synthetic
+from oracle import spectral_ref, vit_ref
+from tests.util import build_w64, check_eigs, d_orthonormality, golden_case
+
+pytestmark = pytest.mark.gpu
+HERE = Path(__file__).resolve().parent
+DEV = "cuda"
+
+
+def test_library_is_the_hip_build():
+    lib = hip.load_library()
+    assert lib.dss_target_arch() == b"gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ----------------------------------------------------------------------------- image transform
+@pytest.mark.parametrize("h,w", [(224, 224), (75, 64), (100, 130), (480, 480), (33, 47)])
+def test_preprocess_chw_bit_exact(h, w):
+    imgs = np.stack([synthetic.synthetic_image(i, h, w) for i in range(2)])
+    out = hip.preprocess_chw(torch.from_numpy(imgs).to(DEV)).cpu()
+    for i in range(2):
+        assert torch.equal(out[i], vit_ref.ref_preprocess(imgs[i]))
+
+
+@pytest.mark.parametrize("h,w,p", [(224, 224, 16), (75, 64, 16), (100, 130, 8), (480, 480, 16), (50, 70, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_preprocess_patchify_bit_exact(h, w, p, dtype):
+    imgs = np.stack([synthetic.synthetic_image(10 + i, h, w) for i in range(2)])
+    out = hip.preprocess_patchify(torch.from_numpy(imgs).to(DEV), p, dtype).cpu()
+    hp, wp = h // p, w // p
+    for i in range(2):
+        x = vit_ref.ref_preprocess(imgs[i])[:, : hp * p, : wp * p]  # crop (extract.py:82-88)
+        ref = x.reshape(3, hp, p, wp, p).permute(1, 3, 0, 2, 4).reshape(hp * wp, 3 * p * p)
+        assert torch.equal(out[i], ref.to(dtype))
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,d", [(901, 384), (3601, 768), (7, 64), (130, 1024), (5, 2048), (1, 4)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_layernorm_matches_fp32_reference(rows, d, out_dtype):
+    g = torch.Generator().manual_seed(rows * 7 + d)
+    x = torch.randn(rows, d, generator=g) * 3 + 0.5
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    ref = F.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-6)
+    xd = x.to(DEV)
+    out = hip.layernorm(xd, gamma.to(DEV), beta.to(DEV), 1e-6, out_dtype).cpu()
+    assert torch.equal(xd.cpu(), x)  # untouched without a residual
+    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}[out_dtype]
+    assert (out.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    if out_dtype == torch.float32:  # the plain-PyTorch fp32 op of the same definition
+        assert (out - F.layer_norm(x, (d,), gamma, beta, 1e-6)).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_layernorm_fused_residual(res_dtype):
+    rows, d = 333, 384
+    g = torch.Generator().manual_seed(5)
+    x, r = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g).to(res_dtype)
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    xd = x.to(DEV)
+    out = hip.layernorm(xd, gamma.to(DEV), beta.to(DEV), 1e-6, torch.float16, residual=r.to(DEV)).cpu()
+    xsum = x + r.float()
+    assert torch.equal(xd.cpu(), xsum)  # residual stream updated in place, one fp32 rounding
+    ref = F.layer_norm(xsum.double(), (d,), gamma.double(), beta.double(), 1e-6)
+    assert (out.double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+
+
+# ----------------------------------------------------------------------------- attention
+def _attention_ref(qkv, heads, scale):
+    b, t, _ = qkv.shape
+    q, k, v = qkv.double().reshape(b, t, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    a = ((q @ k.transpose(-1, -2)) * scale).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(b, t, heads * 64)
+
+
+@pytest.mark.parametrize("b,t,heads", [(2, 901, 6), (1, 197, 6), (1, 17, 2), (1, 64, 1), (1, 65, 1), (3, 130, 12),
+                                        (1, 1, 1), (1, 33, 3), (1, 3601, 2)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_matches_fp64_reference(b, t, heads, dtype):
+    g = torch.Generator().manual_seed(b * 100 + t + heads)
+    qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 1.5).to(dtype)
+    out = hip.attention(qkv.to(DEV), heads, 0.125).cpu()
+    ref = _attention_ref(qkv, heads, 0.125)
+    err = (out.double() - ref).abs().max().item()
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+    assert torch.isfinite(out.float()).all()
+
+
+def test_attention_peaked_rows_force_online_rescale():
+    """One key far above the rest late in the sequence: the running max jumps, exercising the rescale."""
+    b, t, heads = 1, 300, 2
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(b, t, 3, heads, 64, generator=g) * 0.3
+    qkv[0, 250, 1] = qkv[0, 7, 0] * 40.0   # key 250 aligned with query 7 (both heads)
+    qkv[0, 40, 1] = qkv[0, 9, 0] * 25.0
+    qkv = qkv.reshape(b, t, -1).half()
+    out = hip.attention(qkv.to(DEV), heads, 0.125).cpu()
+    ref = _attention_ref(qkv, heads, 0.125)
+    assert (out.double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
+# ----------------------------------------------------------------------------- normalise + affinity
+def test_normalize_rows():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(50, 384, generator=g)
+    x[3] = 0.0
+    x[4] = 1e-20
+    out = hip.normalize_rows(x.to(DEV)).cpu()
+    ref = F.normalize(x, p=2, dim=-1)
+    assert (out - ref).abs().max().item() < 1e-6 and torch.equal(out[3], torch.zeros(384))
+    out2 = hip.normalize_rows(torch.randn(9, 37, generator=g).to(DEV))  # D not a multiple of 4
+    assert abs(out2.norm(dim=-1).mean().item() - 1) < 1e-5
+
+
+@pytest.mark.parametrize("b,n,d", [(2, 900, 384), (1, 713, 384), (1, 16, 32), (1, 64, 64), (1, 65, 32), (3, 129, 768),
+                                    (1, 3600, 768)])
+def test_affinity_matches_fp64(b, n, d):
+    feats = torch.from_numpy(np.stack([synthetic.synthetic_features("blobs" if i % 2 else "random", n, d, 50 + i,
+                                                                     None if int(n ** 0.5) ** 2 == n else (1, n))
+                                       for i in range(b)]))
+    fn = hip.normalize_rows(feats.to(DEV))
+    w = hip.affinity(fn).cpu()
+    ld = hip.affinity_ld(n)
+    assert tuple(w.shape) == (b, n, ld) and ld % 64 == 0 and ld >= n
+    assert torch.equal(w[:, :, n:], torch.zeros(b, n, ld - n))  # pad columns are zero
+    x = F.normalize(feats.double(), dim=-1)
+    ref = (x @ x.transpose(1, 2)).clamp_min(0)
+    assert (w[:, :, :n].double() - ref).abs().max().item() < 2e-6
+    assert torch.equal(w[:, :, :n], w[:, :, :n].transpose(1, 2))  # bit-symmetric (same fmaf chain both ways)
+    wneg = hip.affinity(fn, threshold_at_zero=False).cpu()
+    assert (wneg[:, :, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
+
+
+# ----------------------------------------------------------------------------- eigen stage
+EIG_FILES = sorted(glob.glob(str(HERE / "golden" / "eigs_*.npz")))
+
+
+@pytest.mark.parametrize("path", EIG_FILES, ids=lambda p: p.split("eigs_")[-1][:-4])
+def test_eigs_match_reference_goldens(path):
+    feats, K, ref_lam, ref_vec, _ = golden_case(path)
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
+    assert info.item() > 0
+    assert vec.dtype == torch.float32 and tuple(vec.shape) == (1, K, feats.shape[0]) and tuple(ev.shape) == (1, K)
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), ref_vec, ref_lam, what=path)
+    if feats.shape[0] <= 1600:
+        _, d = build_w64(feats)
+        assert d_orthonormality(vec[0].cpu().numpy(), d=d) < 1e-4  # v^T D v = 1 like ARPACK with M=D
+    for k in range(K):
+        assert not (0.5 < (vec[0, k] > 0).float().mean().item() < 1.0)  # sign-rule post-condition
+
+
+def test_eigs_batch_against_oracle():
+    """A batch of different images in ONE launch vs the scipy oracle image by image."""
+    n, d, K, b = 400, 384, 5, 9
+    feats = np.stack([synthetic.synthetic_features("blobs", n, d, 900 + i, (20, 20)) for i in range(b)])
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), K)
+    assert (info > 0).all()
+    for i in range(b):
+        lam, v = spectral_ref.ref_laplacian_eigs(torch.from_numpy(feats[i])[None], K)
+        check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"img{i}")
+
+
+@pytest.mark.parametrize("n,d,K", [(16, 32, 5), (12, 32, 3), (70, 64, 1), (70, 64, 2), (196, 384, 20), (333, 96, 7)])
+def test_eigs_edge_shapes_against_fp64(n, d, K):
+    feats = synthetic.synthetic_features("random", n, d, 4000 + n + K)
+    lam64, v64 = spectral_ref.dense_f64_eigs(feats, K)
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
+    assert info.item() > 0
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v64, lam64, what=f"n{n}K{K}")
+
+
+def test_eigs_rejects_bad_arguments_and_reports_nonconvergence():
+    feats = torch.from_numpy(synthetic.synthetic_features("random", 900, 384, 201, (30, 30)))[None].to(DEV)
+    with pytest.raises(ValueError):
+        spectral.laplacian_eigs_from_features(feats[:, :5], 5)
+    with pytest.raises(spectral.EigsNotConverged):
+        spectral.laplacian_eigs_from_features(feats, 5, max_restarts=1)
+    ev, vec, info = spectral.laplacian_eigs_from_features(feats, 5, max_restarts=1, strict=False)
+    assert info.item() < 0 and torch.isfinite(vec).all()
+    w = hip.affinity(hip.normalize_rows(feats))
+    with pytest.raises(hip.HipLibraryError):
+        hip.laplacian_eigs(w, 900, 40, ncv=30)  # Krylov dimension too small for K
+
+
+def test_eigs_large_image_properties():
+    """BASELINE config 5's largest shape (N = 6400, K = 20): too slow for scipy in a test; size-independent
+    properties instead - generalized residual, D-orthonormality, ascending eigenvalues, constant v0."""
+    n, d, K = 6400, 768, 20
+    feats = torch.from_numpy(synthetic.synthetic_features("blobs", n, d, 77, (80, 80)))[None].to(DEV)
+    ev, vec, info = spectral.laplacian_eigs_from_features(feats, K)
+    assert info.item() > 0
+    x = F.normalize(feats[0].double(), dim=-1)
+    w = (x @ x.T).clamp_min(0)
+    dd = w.sum(1)
+    v, lam = vec[0].double(), ev[0].double()
+    res = (dd[None] * v - v @ w) - lam[:, None] * dd[None] * v     # (D - W) v - lambda D v, row form
+    assert (res.norm(dim=1) / dd.sqrt().norm()).max().item() < 1e-4
+    gram = (v * dd[None]) @ v.T
+    assert (gram - torch.eye(K, device=DEV, dtype=torch.float64)).abs().max().item() < 1e-4
+    assert (lam[1:] >= lam[:-1] - 1e-6).all() and abs(lam[0].item()) < 1e-5
+    assert (v[0].std() / v[0].mean().abs()).item() < 1e-3
+
+
+def test_sign_rule_kernel():
+    v = torch.tensor([[1.0, 1.0, 1.0, -1.0], [1.0, 1.0, -1.0, -1.0], [1.0, 1.0, 1.0, 1.0],
+                      [-1.0, -1.0, -1.0, 1.0], [0.0, 1.0, 1.0, 1.0]])
+    out = hip.sign_rule_(v.clone().to(DEV)).cpu()
+    assert torch.equal(out, spectral_ref.ref_sign_rule(v.clone()))
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn(6, 901, generator=g)
+    assert torch.equal(hip.sign_rule_(big.clone().to(DEV)).cpu(), spectral_ref.ref_sign_rule(big.clone()))
