@@ -112,7 +112,8 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals):
         ce = spectral_ref.cos_err(gpu_vecs[i].cpu().numpy(), vec.numpy())
         worst = max(worst, float(ce.max()))
         try:
-            check_eigs(gpu_vecs[i].cpu().numpy(), gpu_vals[i].cpu().numpy(), vec.numpy(), lam.numpy(), what=f"img{i}")
+            check_eigs(gpu_vecs[i].cpu().numpy(), gpu_vals[i].cpu().numpy(), vec.numpy(), lam.numpy(), what=f"img{i}",
+                       lam_tol=1e-2)  # eigenvalues carry the half-precision feature error; vectors: 1e-4
         except AssertionError as e:
             ok = False
             print(f"[bench] parity failure: {e}", file=sys.stderr)

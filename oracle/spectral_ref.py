@@ -9,7 +9,7 @@ Follows, line by line:
   extract/extract.py:191-195   W = F F^T ; W *= (W > 0) ; W /= W.max() ; to numpy
   extract/extract.py:215-222   W_color = 0 ; W_comb = W ; D = get_diagonal(W_comb).todense()
   extract/extract_utils.py:207-220  d = row_sum(W) ; d[d < 1e-12] = 1 ; diags(d)
-  extract/extract.py:227       eigsh(D - W, k=K, sigma=0, which='LM', M=D)
+  extract/extract.py:226-229   try eigsh(D - W, k=K, sigma=0, which='LM', M=D) except: eigsh(..., which='SM', M=D)
   extract/extract.py:235       eigenvectors.T -> float32 [K, N]
   extract/extract.py:238-240   sign rule
 Third-party arithmetic reached by those lines and absent from /root/reference:
@@ -66,7 +66,10 @@ def ref_laplacian_eigs(feats: torch.Tensor, K: int, normalize: bool = True,
     w = ref_affinity(feats, normalize, threshold_at_zero)
     d = ref_degree(w)
     dmat = np.diag(d)  # == np.array(scipy.sparse.diags(d).todense())
-    eigenvalues, eigenvectors = eigsh(dmat - w, k=K, sigma=0, which="LM", M=dmat)
+    try:  # extract.py:226-229: shift-invert first; ANY failure (e.g. an exactly singular LU) -> 'SM' mode
+        eigenvalues, eigenvectors = eigsh(dmat - w, k=K, sigma=0, which="LM", M=dmat)
+    except Exception:
+        eigenvalues, eigenvectors = eigsh(dmat - w, k=K, which="SM", M=dmat)
     eigenvalues = torch.from_numpy(eigenvalues)
     eigenvectors = torch.from_numpy(eigenvectors.T).float()
     return eigenvalues, ref_sign_rule(eigenvectors)

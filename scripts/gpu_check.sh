@@ -7,9 +7,9 @@ STAGE=${1:-all}
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
 nproc >> gpurun_out/gpu.txt
 if [[ $STAGE == all || $STAGE == tests ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -60 > gpurun_out/pytest_gpu.log
+  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log
   echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
-  tail -25 gpurun_out/pytest_gpu.log
+  tail -60 gpurun_out/pytest_gpu.log
 fi
 if [[ $STAGE == all || $STAGE == smoke ]]; then
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?" >> gpurun_out/smoke.log
@@ -18,4 +18,13 @@ fi
 if [[ $STAGE == all || $STAGE == bench ]]; then
   timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?" >> gpurun_out/bench.err
   tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json
+fi
+if [[ $STAGE == prof ]]; then
+  # per-kernel time of the bench command (rocprofv3 kernel trace + stats); summaries are copied to profiles/ by hand
+  REPO_DIR=$PWD
+  rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO_DIR/gpurun_out/prof -o bench -- python $REPO_DIR/bench.py --steps 2 --warmup 1 --cpu-images 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/prof/bench.json 2> $REPO_DIR/gpurun_out/prof/bench.err)
+  echo "prof exit: $?"; cat gpurun_out/prof/bench.json; find gpurun_out/prof -name "*stats*" | head
+  # keep only the small summaries (the raw kernel trace is large)
+  find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi

