@@ -38,10 +38,10 @@ MFMA32_PEAK_TF = 157.3      # fp32 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
-    ap.add_argument("--vit-batch", type=int, default=64, help="images per ViT forward")
+    ap.add_argument("--vit-batch", type=int, default=128, help="images per ViT forward")
     ap.add_argument("--model", default="dino_vits16")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--K", type=int, default=5)
@@ -90,6 +90,22 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
         out[name] = entry
     return out
+
+
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary whose workload matches
+    this run (profiles/rNN_pmc_traffic.json, FETCH_SIZE already doubled per the gfx950 correction); else None."""
+    best = None
+    for f in sorted((REPO / "profiles").glob("r*_pmc_traffic.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        c = d.get("config", {})
+        if (c.get("model"), c.get("size"), c.get("K"), c.get("batch"), c.get("vit_batch")) == \
+                (a.model, a.size, a.K, a.batch, a.vit_batch) and kernel in d.get("kernels", {}):
+            best = {"bytes_per_launch": d["kernels"][kernel]["hbm_bytes_per_launch"], "source": f"profiles/{f.name}"}
+    return best
 
 
 def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals):
@@ -157,6 +173,7 @@ def main():
     for s in range(a.steps):
         ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch)
         results.append((ev, vec, info))
+    host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
     ev = torch.cat([r[0] for r in results])
     vec = torch.cat([r[1] for r in results])
     ids = torch.arange(ev.shape[0], device=dev) * world + rank
@@ -180,7 +197,7 @@ def main():
         dominant = max((k for k in kern if "achieved" in kern[k]), key=lambda k: kern[k]["total_ms"])
         d = kern[dominant]
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": None}
+                    "unit": d["unit"], "frac": d["frac"], "traffic": pmc_traffic(dominant, a)}
         out = {
             "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
             "value": round(a.steps * a.batch * world / elapsed, 2), "unit": "images/s",
@@ -192,6 +209,7 @@ def main():
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
                        "accumulate": "fp32", "eig_dtype": "f32", "parallelism": f"dp{world} round-robin, 1 gather"},
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
+            "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),
         }
         if world == 1 and a.cpu_images > 0:
             first = step(model, pool[: a.cpu_images + 1], a.K, a.vit_batch)

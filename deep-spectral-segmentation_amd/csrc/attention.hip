@@ -28,6 +28,8 @@
 //   key(r) = (r&3) + 8*(r>>2) + 4*hh,  r = 0..15  of the 32-key block.  Registers 8t..8t+7 (t = 0,1) form
 // the B operand of P.V MFMA number t, i.e. operand slot (hh, e) carries key 16t + 8*(e>>2) + 4*hh + (e&3).
 // V^T therefore stores, at position 16t + 8*hh + e of each 32-key block, exactly that key.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dss {
@@ -193,9 +195,210 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Qp,
   }
 }
 
+
+// ================================================================================================
+// v2: LDS-staged, 64 queries per wave, no pack pass.
+//   * block = 4 waves = 256 query rows of one (image, head); K and V tiles of 64 keys are read ONCE per
+//     block straight from the qkv tensor (16 B/lane, 128-B row segments), staged through registers into a
+//     double-buffered LDS image and shared by the 4 waves (one barrier per tile; the next tile's global
+//     loads are issued before the MFMAs of the current one and written to LDS after them).
+//   * K tile row-major, row stride 144 B: the ds_read_b128 operand reads (16 lanes = 16 rows) land on 16
+//     distinct 4-bank slots.  V tile row-major, row stride 192 B, read with ds_read_b64_tr_b16: inside
+//     a 16-lane group lane i supplies the address of (row i>>2, cols 4*(i&3)..+3) of a [4 keys x 16 dh]
+//     block and receives column i (verified on hardware, scripts/probes/tr16_probe.hip) - the hardware
+//     transpose turns row-major V into the V^T fragment the P.V MFMA needs; 192 B puts the 4 rows of a
+//     block on disjoint bank quarters.
+//   * each wave holds TWO 32-query blocks, so every K / V^T fragment read from LDS feeds two MFMAs.
+template <class T>
+__device__ __forceinline__ typename vec8<T>::type lds_read_tr_pair(const T* p_lo, const T* p_hi) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p_lo));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p_hi));
+  const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename vec8<T>::type, c);
+}
+
+static constexpr int KLD = 72;   // halves per K row in LDS (144 B)
+static constexpr int VLD = 96;   // halves per V row in LDS (192 B)
+
+template <class T>
+__device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& lsum, f32x16& o0, f32x16& o1,
+                                              typename vec8<T>::type& pb0, typename vec8<T>::type& pb1,
+                                              float scale_log2, bool tail, int key0, int hh, int Tn) {
+  float mx = -1.0e30f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = s[r] * scale_log2;
+    if (tail) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (key >= Tn) v = -INFINITY;
+    }
+    s[r] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m, mx);
+  const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+  float rs = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+    rs += s[r];
+  }
+  rs += __shfl_xor(rs, 32, 64);
+  lsum = lsum * alpha + rs;
+  m = m_new;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pb0[e] = from_f32<T>(s[e]);
+    pb1[e] = from_f32<T>(s[8 + e]);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+                                                           int heads, float scale_log2) {
+  typedef typename vec8<T>::type V8;
+  typedef typename vec4<T>::type V4;
+  __shared__ __attribute__((aligned(16))) T Ks[2][64 * KLD];
+  __shared__ __attribute__((aligned(16))) T Vs[2][64 * VLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const long rs = 3L * heads * DH;                                  // qkv row stride (halves)
+  const T* base = qkv + (long)b * Tn * rs + (long)head * DH;       // q of token 0; k at +heads*DH, v at +2*heads*DH
+  const int q0 = blockIdx.x * 256 + wave * 64;
+  const bool active = q0 < Tn;                                      // wave-uniform
+
+  // ---- Q fragments (registers, once): lane -> query row q0 + 32*qb + li, dh slice 16*s + 8*hh ----------
+  V8 qf0[4], qf1[4];
+  {
+    int qa = q0 + li, qb = q0 + 32 + li;
+    qa = qa < Tn ? qa : Tn - 1;
+    qb = qb < Tn ? qb : Tn - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf0[s] = *reinterpret_cast<const V8*>(base + (long)qa * rs + 16 * s + 8 * hh);
+      qf1[s] = *reinterpret_cast<const V8*>(base + (long)qb * rs + 16 * s + 8 * hh);
+    }
+  }
+  // ---- staging map: chunk c = tid + 256*j (j = 0,1): row c>>3, 8 halves at column 8*(c&7) ---------------
+  const int srow0 = tid >> 3, scol = (tid & 7) * 8;
+  V8 kreg[2], vreg[2];
+  auto stage_load = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = kt * 64 + srow0 + 32 * j;
+      if (key < Tn) {
+        const T* p = base + (long)key * rs + scol;
+        kreg[j] = *reinterpret_cast<const V8*>(p + (long)heads * DH);
+        vreg[j] = *reinterpret_cast<const V8*>(p + 2L * heads * DH);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kreg[j][i] = (T)0.f; vreg[j][i] = (T)0.f; }
+      }
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = srow0 + 32 * j;
+      *reinterpret_cast<V8*>(&Ks[buf][r * KLD + scol]) = kreg[j];
+      *reinterpret_cast<V8*>(&Vs[buf][r * VLD + scol]) = vreg[j];
+    }
+  };
+
+  f32x16 oa0, oa1, ob0, ob1;   // O^T accumulators: query block a/b x dh block 0/1
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
+  float ma = -1.0e30f, la = 0.f, mb = -1.0e30f, lb = 0.f;
+
+  const int nkt = (Tn + 63) / 64;
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  // per-lane constants of the transposed V read: 16-lane group g = lane>>4, i = lane&15
+  const int tr_row = 4 * hh + ((lane & 15) >> 2);           // + 16*t (+8 for the second half)
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // + 32*db
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage_load(kt + 1);
+    if (active) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int key0 = kt * 64 + half * 32;
+        if (key0 < Tn) {
+          f32x16 sa, sb;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+          const T* krow = &Ks[buf][(half * 32 + li) * KLD + 8 * hh];
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) {
+            const V8 kf = *reinterpret_cast<const V8*>(krow + 16 * sl);
+            sa = mfma32x32x16(kf, qf0[sl], sa);
+            sb = mfma32x32x16(kf, qf1[sl], sb);
+          }
+          const bool tail = key0 + 32 > Tn;
+          V8 pa0, pa1, pb0, pb1;
+          softmax_block<T>(sa, ma, la, oa0, oa1, pa0, pa1, scale_log2, tail, key0, hh, Tn);
+          softmax_block<T>(sb, mb, lb, ob0, ob1, pb0, pb1, scale_log2, tail, key0, hh, Tn);
+          const T* vbase = &Vs[buf][(half * 32 + tr_row) * VLD + tr_col];
+          {  // t = 0 (keys 0..15 of the block), dh blocks 0 and 1
+            const V8 v0 = lds_read_tr_pair<T>(vbase, vbase + 8 * VLD);
+            const V8 v1 = lds_read_tr_pair<T>(vbase + 32, vbase + 8 * VLD + 32);
+            oa0 = mfma32x32x16(v0, pa0, oa0);
+            ob0 = mfma32x32x16(v0, pb0, ob0);
+            oa1 = mfma32x32x16(v1, pa0, oa1);
+            ob1 = mfma32x32x16(v1, pb0, ob1);
+          }
+          {  // t = 1 (keys 16..31)
+            const V8 v0 = lds_read_tr_pair<T>(vbase + 16 * VLD, vbase + 24 * VLD);
+            const V8 v1 = lds_read_tr_pair<T>(vbase + 16 * VLD + 32, vbase + 24 * VLD + 32);
+            oa0 = mfma32x32x16(v0, pa1, oa0);
+            ob0 = mfma32x32x16(v0, pb1, ob0);
+            oa1 = mfma32x32x16(v1, pa1, oa1);
+            ob1 = mfma32x32x16(v1, pb1, ob1);
+          }
+        }
+      }
+    }
+    if (kt + 1 < nkt) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!active) return;
+  auto store_q = [&](int q, const f32x16& x0, const f32x16& x1, float l) {
+    if (q >= Tn) return;
+    const float inv = 1.0f / l;
+    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      V4 a, c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = from_f32<T>(x0[4 * g + i] * inv);
+        c[i] = from_f32<T>(x1[4 * g + i] * inv);
+      }
+      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
+      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = c;
+    }
+  };
+  store_q(q0 + li, oa0, oa1, la);
+  store_q(q0 + 32 + li, ob0, ob1, lb);
+}
+
 template <class T>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, void* ws,
-                             hipStream_t s) {
+                             hipStream_t s, int impl) {
+  if (impl != 1) {  // v2 (default): LDS-staged, no pack pass, workspace unused
+    hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3(ceil_div(Tn, 256), heads, B), dim3(256), 0, s, (const T*)qkv,
+                       (T*)out, Tn, heads, scale * 1.4426950408889634f);
+    return;
+  }
   const int Tp = attn_tp(Tn);
   const size_t panel = (size_t)B * heads * Tp * DH;
   T* Qp = (T*)ws;
@@ -224,9 +427,11 @@ extern "C" int dss_attention_fwd(const void* qkv, void* out, int B, int T, int h
     return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes,
                      dss_attention_workspace_bytes(B, T, heads));
   hipStream_t s = (hipStream_t)stream;
+  const char* env = getenv("DSS_ATTENTION_IMPL");  // 1 = v1 (pack + register-direct), anything else = v2
+  const int impl = env ? atoi(env) : 2;
   switch (dtype) {
-    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s); break;
-    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s); break;
+    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;
+    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;
     default: return dss::fail(DSS_ERR_BAD_ARG, "dss_attention_fwd: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
   }
   DSS_CHECK_LAUNCH("attention");

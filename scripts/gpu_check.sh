@@ -27,4 +27,17 @@ if [[ $STAGE == prof ]]; then
   echo "prof exit: $?"; cat gpurun_out/prof/bench.json; find gpurun_out/prof -name "*stats*" | head
   # keep only the small summaries (the raw kernel trace is large)
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
+  python scripts/rocpd_summary.py gpurun_out/prof/bench_results.db > gpurun_out/prof/kernel_stats.csv; head -14 gpurun_out/prof/kernel_stats.csv
+fi
+if [[ $STAGE == pmc ]]; then
+  # HBM traffic counters, one rocprofv3 pass per counter (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2;
+  # MI355X_MICROARCH.md "rocprofv3 PMC slots"); kernel-trace only, no other trace domains.
+  REPO_DIR=$PWD
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$C && mkdir -p gpurun_out/pmc_$C
+    (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace -d $REPO_DIR/gpurun_out/pmc_$C -o pmc -- python $REPO_DIR/bench.py --steps 2 --warmup 1 --cpu-images 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/pmc_$C/bench.json 2> $REPO_DIR/gpurun_out/pmc_$C/bench.err)
+    echo "pmc $C exit: $?"
+    python scripts/rocpd_pmc.py gpurun_out/pmc_$C/pmc_results.db $C > gpurun_out/pmc_$C/pmc_$C.csv; head -12 gpurun_out/pmc_$C/pmc_$C.csv
+    [ -s gpurun_out/pmc_$C/pmc_$C.csv ] && [ $(wc -l < gpurun_out/pmc_$C/pmc_$C.csv) -gt 2 ] && rm -f gpurun_out/pmc_$C/pmc_results.db
+  done
 fi

@@ -85,9 +85,11 @@ def _attention_ref(qkv, heads, scale):
 
 
 @pytest.mark.parametrize("b,t,heads", [(2, 901, 6), (1, 197, 6), (1, 17, 2), (1, 64, 1), (1, 65, 1), (3, 130, 12),
-                                        (1, 1, 1), (1, 33, 3), (1, 3601, 2)])
+                                        (1, 1, 1), (1, 33, 3), (1, 3601, 2), (2, 257, 2), (1, 320, 1)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_attention_matches_fp64_reference(b, t, heads, dtype):
+@pytest.mark.parametrize("impl", ["2", "1"])  # 2 = LDS-staged kernel (default), 1 = pack + register-direct kernel
+def test_attention_matches_fp64_reference(b, t, heads, dtype, impl, monkeypatch):
+    monkeypatch.setenv("DSS_ATTENTION_IMPL", impl)
     g = torch.Generator().manual_seed(b * 100 + t + heads)
     qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 1.5).to(dtype)
     out = hip.attention(qkv.to(DEV), heads, 0.125).cpu()
@@ -98,8 +100,10 @@ def test_attention_matches_fp64_reference(b, t, heads, dtype):
     assert torch.isfinite(out.float()).all()
 
 
-def test_attention_peaked_rows_force_online_rescale():
+@pytest.mark.parametrize("impl", ["2", "1"])
+def test_attention_peaked_rows_force_online_rescale(impl, monkeypatch):
     """One key far above the rest late in the sequence: the running max jumps, exercising the rescale."""
+    monkeypatch.setenv("DSS_ATTENTION_IMPL", impl)
     b, t, heads = 1, 300, 2
     g = torch.Generator().manual_seed(3)
     qkv = torch.randn(b, t, 3, heads, 64, generator=g) * 0.3
