@@ -5,7 +5,7 @@ and a CPU baseline (the oracle, i.e. the reference's numpy/scipy/torch-CPU path)
     python bench.py [--gpus N --steps K --warmup W]          # N=1 directly; N>1 under torch.distributed.run
 
 Workload (BASELINE.json configs[1]): dino_vits16, 480x480 synthetic VOC-shaped images, K=5.
-One STEP = one batch of ``--batch`` images (default 256) already resident in HBM as uint8 HWC:
+One STEP = one batch of ``--batch`` images (default 1024) already resident in HBM as uint8 HWC:
 transform+crop+im2col -> ViT (HIP LayerNorm/attention, hipBLASLt GEMMs) -> K features -> normalise ->
 affinity -> Lanczos eigenpairs -> [K, N] eigenvectors.  One ``B=1`` result per image, like the reference.
 Multi-GPU: every rank runs the same number of steps on its own images (weak scaling, no collective on the
@@ -38,9 +38,9 @@ MFMA32_PEAK_TF = 157.3      # fp32 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per step per GPU")
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
     ap.add_argument("--vit-batch", type=int, default=128, help="images per ViT forward")
     ap.add_argument("--model", default="dino_vits16")
     ap.add_argument("--size", type=int, default=480)
@@ -160,8 +160,11 @@ def main():
         idx = (torch.arange(a.batch, device=dev) + s * a.batch) % n_distinct
         return pool[idx]
 
+    from dss_amd.vit import setup_gemm_tuning
+    setup_gemm_tuning(tune_new_shapes=True)   # warm-up may pick GEMM solutions for shapes missing from the shipped table
     for s in range(a.warmup):
         step(model, batch_for(s), a.K, a.vit_batch)
+    setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
@@ -186,7 +189,8 @@ def main():
     elapsed = time.perf_counter() - t0
     timers, hip.TIMERS = hip.TIMERS, None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tdev = dev if torch.distributed.get_backend() != "gloo" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -260,7 +260,7 @@ __device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& lsum, 
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
-                                                           int heads, float scale_log2) {
+                                                           int heads, int nb, int nqb, float scale_log2) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
   __shared__ __attribute__((aligned(16))) T Ks[2][64 * KLD];
@@ -268,10 +268,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order (1-D grid).  Workgroup id -> XCD is observed round-robin (id % 8) and every XCD has
+  // its own L2: the nqb query-blocks of one (image, head) are given ids that are congruent mod 8, so they run
+  // on ONE XCD close in time and its L2 serves K/V to all of them (PMC before: K/V fetched nqb x from HBM).
+  // Pure speed heuristic - any placement is correct.
+  int qblk, group;
+  {
+    const int id = blockIdx.x, groups = heads * nb, g8 = groups & ~7;
+    if (id < nqb * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      group = (slot / nqb) * 8 + xcd;
+      qblk = slot % nqb;
+    } else {
+      const int r = id - nqb * g8;
+      group = g8 + r / nqb;
+      qblk = r % nqb;
+    }
+  }
+  const int head = group % heads, b = group / heads;
   const long rs = 3L * heads * DH;                                  // qkv row stride (halves)
   const T* base = qkv + (long)b * Tn * rs + (long)head * DH;       // q of token 0; k at +heads*DH, v at +2*heads*DH
-  const int q0 = blockIdx.x * 256 + wave * 64;
+  const int q0 = qblk * 256 + wave * 64;
   const bool active = q0 < Tn;                                      // wave-uniform
 
   // ---- Q fragments (registers, once): lane -> query row q0 + 32*qb + li, dh slice 16*s + 8*hh ----------
@@ -395,8 +412,9 @@ template <class T>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, void* ws,
                              hipStream_t s, int impl) {
   if (impl != 1) {  // v2 (default): LDS-staged, no pack pass, workspace unused
-    hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3(ceil_div(Tn, 256), heads, B), dim3(256), 0, s, (const T*)qkv,
-                       (T*)out, Tn, heads, scale * 1.4426950408889634f);
+    const int nqb = ceil_div(Tn, 256);
+    hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(256), 0, s, (const T*)qkv,
+                       (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f);
     return;
   }
   const int Tp = attn_tp(Tn);
@@ -411,24 +429,30 @@ static void launch_attention(const void* qkv, void* out, int B, int Tn, int head
                      (T*)out, Tn, Tp, heads, scale_log2);
 }
 
+// DSS_ATTENTION_IMPL=1 selects the v1 kernel pair (pack + register-direct); anything else the LDS-staged v2.
+static int attention_impl() {
+  const char* env = getenv("DSS_ATTENTION_IMPL");
+  return env ? atoi(env) : 2;
+}
+
 }  // namespace dss
 
 extern "C" size_t dss_attention_workspace_bytes(int B, int T, int heads) {
   if (B <= 0 || T <= 0 || heads <= 0) return 0;
+  if (dss::attention_impl() != 1) return 0;  // the default LDS-staged kernel reads qkv in place
   return (size_t)3 * B * heads * dss::attn_tp(T) * dss::DH * 2;
 }
 
 extern "C" int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale,
                                  int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  DSS_REQUIRE(qkv && out && workspace, "dss_attention_fwd: null pointer");
+  DSS_REQUIRE(qkv && out, "dss_attention_fwd: null pointer");
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
   DSS_REQUIRE(B <= 65535 && heads <= 65535, "dss_attention_fwd: B and heads must be <= 65535");
-  if (workspace_bytes < dss_attention_workspace_bytes(B, T, heads))
-    return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes,
-                     dss_attention_workspace_bytes(B, T, heads));
+  const size_t need = dss_attention_workspace_bytes(B, T, heads);
+  if (need && (!workspace || workspace_bytes < need))
+    return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
-  const char* env = getenv("DSS_ATTENTION_IMPL");  // 1 = v1 (pack + register-direct), anything else = v2
-  const int impl = env ? atoi(env) : 2;
+  const int impl = dss::attention_impl();
   switch (dtype) {
     case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;
     case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;

@@ -1,11 +1,13 @@
 // eigs.hip - kernel wrappers + C ABI for the Laplacian eigen stage (algorithm: eigs_core.h) and the
 // stand-alone sign rule.
+#include <stdlib.h>
+
 #include "common.h"
 #include "eigs_core.h"
 
 namespace dss {
 
-static constexpr int EIGS_THREADS = 1024;  // 16 waves: enough 16-byte loads in flight to stream W per CU
+static constexpr int EIGS_THREADS = 1024;  // upper bound of the launch (register budget: 128 VGPRs)
 
 __global__ __launch_bounds__(EIGS_THREADS) void laplacian_eigs_kernel(const float* __restrict__ W, EigsParams P,
                                                                       float* gws, size_t gws_stride,
@@ -73,7 +75,12 @@ extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* ei
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
   if (e != hipSuccess)
     return dss::fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
-  hipLaunchKernelGGL(dss::laplacian_eigs_kernel, dim3(B), dim3(dss::EIGS_THREADS), L.total, (hipStream_t)stream,
+  // 512-thread workgroups (default) let two images share a CU: the serial Rayleigh-Ritz / restart phases of one
+  // overlap the W streaming of the other.  DSS_EIGS_THREADS=1024 selects one 16-wave workgroup per CU.
+  const char* env = getenv("DSS_EIGS_THREADS");
+  int threads = env ? atoi(env) : 512;
+  if (threads != 256 && threads != 512 && threads != 1024) threads = 512;
+  hipLaunchKernelGGL(dss::laplacian_eigs_kernel, dim3(B), dim3(threads), L.total, (hipStream_t)stream,
                      W, P, (float*)workspace, per_img, eigenvalues, eigenvectors, info);
   DSS_CHECK_LAUNCH("laplacian_eigs");
   return DSS_OK;

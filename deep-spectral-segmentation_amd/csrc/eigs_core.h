@@ -55,7 +55,6 @@
 namespace dss {
 
 static constexpr int EIGS_MAX_NCV = 64;
-static constexpr double EIGS_SHIFT = 2.0;  // spectrum of S is in [-1, 1]: S + 2I has eigenvalues in [1, 3]
 
 struct EigsParams {
   int N;            // matrix order (patches)
@@ -80,14 +79,14 @@ DSS_HD inline EigsLds eigs_lds_layout(int ld, int ncv) {
   L.off_ws = o; o += (size_t)ld * 4;
   L.off_A = o; o += (size_t)ncv * ncv * 8;
   L.off_V = o; o += (size_t)ncv * ncv * 8;
-  L.off_small = o; o += 4096;
+  L.off_small = o; o += 6144;
   L.total = o;
   return L;
 }
 // global workspace per image (floats): two basis buffers [(ncv+1) x ld] + dis[ld]
 DSS_HD inline size_t eigs_ws_floats_per_image(int ld, int ncv) { return (size_t)2 * (ncv + 1) * ld + ld; }
 
-struct EigsSmall {  // lives in LDS at off_small (<= 4096 B)
+struct EigsSmall {  // lives in LDS at off_small (<= 6144 B)
   double alpha[EIGS_MAX_NCV];   // T diagonal
   double beta[EIGS_MAX_NCV];    // T[j][j+1] for j >= l
   double arrow[EIGS_MAX_NCV];   // T[i][l] for i < l (after a restart)
@@ -95,7 +94,8 @@ struct EigsSmall {  // lives in LDS at off_small (<= 4096 B)
   float coef[EIGS_MAX_NCV + 1]; // Gram-Schmidt coefficients
   int perm[EIGS_MAX_NCV];       // perm[rank] = column index, Ritz values descending
   float red[64];                // cross-wave reduction scratch
-  double redd[64];
+  double jc[EIGS_MAX_NCV / 2], js[EIGS_MAX_NCV / 2];  // Jacobi rotations of the current round
+  int jp[EIGS_MAX_NCV / 2], jq[EIGS_MAX_NCV / 2];
   int flag;
 };
 
@@ -201,56 +201,68 @@ DSS_DEV void basis_axpy(const float* V, int ldv, int nvec, float* ws, int N, con
   }
 }
 
-// Symmetric eigen-decomposition of the (m x m) projected matrix by one-sided (Hestenes) Jacobi on
-// A = T + shift*I (positive definite, condition <= 3) in fp64.  Column pairs of a round are disjoint:
-// one wave per pair, one lane per matrix row.  A and Vr are column-major [col][row] with leading dim m.
-// On exit theta[c] = |A_c| - shift, Vr[:, c] = eigenvector, perm = ranks (descending theta).
+// Symmetric eigen-decomposition of the (m x m) projected matrix by the classical two-sided Jacobi method with
+// a parallel (round-robin) ordering, fp64, entirely in LDS.  A round rotates M/2 DISJOINT index pairs at once:
+//   1. one thread per pair: (c, s) from a_pp, a_qq, a_pq                       - no reductions at all
+//   2. one thread per (row, pair): columns p,q of A and of the accumulated V   (A <- A J, V <- V J)
+//   3. one thread per (pair, column): rows p,q of A                            (A <- J^T A)
+// with a barrier after each step.  A and Vr are column-major with leading dimension m (A is symmetric).
+// On exit theta[c] = A[c][c], Vr[:, c] = eigenvector, perm = ranks (descending theta).
 DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm) {
-  const int M = (m + 1) & ~1;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    float off = 0.f;
+  const int M = (m + 1) & ~1, np = M / 2;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    if (DSS_TID == 0) sm->flag = 0;
+    DSS_SYNC();
     for (int round = 0; round < M - 1; ++round) {
-      for (int k = DSS_WAVE; k < M / 2; k += DSS_NWAVES) {
+      for (int k = DSS_TID; k < np; k += DSS_NT) {
         int p, q;
         if (k == 0) { p = M - 1; q = round; }
         else { p = (round + k) % (M - 1); q = (round - k + (M - 1)) % (M - 1); }
-        if (p >= m || q >= m) continue;
-        if (p > q) { int t = p; p = q; q = t; }
-        double* ap = A + (size_t)p * m; double* aq = A + (size_t)q * m;
-        double* vp = Vr + (size_t)p * m; double* vq = Vr + (size_t)q * m;
-        double spp = 0., sqq = 0., spq = 0.;
-        for (int i = DSS_LANE; i < m; i += DSS_LANES) {
-          const double x = ap[i], y = aq[i];
-          spp += x * x; sqq += y * y; spq += x * y;
-        }
-        spp = DSS_WAVE_SUM(spp); sqq = DSS_WAVE_SUM(sqq); spq = DSS_WAVE_SUM(spq);
-        const double denom = sqrt(spp * sqq);
-        const double rel = denom > 0. ? fabs(spq) / denom : 0.;
-        off = fmaxf(off, (float)rel);
-        if (rel > 1e-15) {
-          const double zeta = (sqq - spp) / (2.0 * spq);
-          const double t = (zeta >= 0. ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-          for (int i = DSS_LANE; i < m; i += DSS_LANES) {
-            const double x = ap[i], y = aq[i];
-            ap[i] = c * x - s * y; aq[i] = s * x + c * y;
-            const double u = vp[i], w = vq[i];
-            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, sn = 0.0;
+        if (q < m) {
+          const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q], apq = A[(size_t)q * m + p];
+          if (fabs(apq) > 1e-17 + 1e-15 * sqrt(fabs(app * aqq))) {
+            const double zeta = (aqq - app) / (2.0 * apq);
+            const double t = (zeta >= 0. ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            sn = c * t;
+            sm->flag = 1;  // benign race: every writer stores 1
           }
+        } else {
+          q = p;  // dummy pair (odd m): identity
         }
+        sm->jp[k] = p; sm->jq[k] = q; sm->jc[k] = c; sm->js[k] = sn;
+      }
+      DSS_SYNC();
+      for (int idx = DSS_TID; idx < np * m; idx += DSS_NT) {  // columns p,q of A and V, one row each
+        const int k = idx / m, r = idx - k * m;
+        const int p = sm->jp[k], q = sm->jq[k];
+        if (p == q) continue;
+        const double c = sm->jc[k], sn = sm->js[k];
+        const double ap = A[(size_t)p * m + r], aq = A[(size_t)q * m + r];
+        A[(size_t)p * m + r] = c * ap - sn * aq;
+        A[(size_t)q * m + r] = sn * ap + c * aq;
+        const double vp = Vr[(size_t)p * m + r], vq = Vr[(size_t)q * m + r];
+        Vr[(size_t)p * m + r] = c * vp - sn * vq;
+        Vr[(size_t)q * m + r] = sn * vp + c * vq;
+      }
+      DSS_SYNC();
+      for (int idx = DSS_TID; idx < np * m; idx += DSS_NT) {  // rows p,q of A, one column each
+        const int k = idx / m, col = idx - k * m;
+        const int p = sm->jp[k], q = sm->jq[k];
+        if (p == q) continue;
+        const double c = sm->jc[k], sn = sm->js[k];
+        const double ap = A[(size_t)col * m + p], aq = A[(size_t)col * m + q];
+        A[(size_t)col * m + p] = c * ap - sn * aq;
+        A[(size_t)col * m + q] = sn * ap + c * aq;
       }
       DSS_SYNC();
     }
-    off = block_max(off, sm);
-    if (off < 1e-13f) break;
+    if (sm->flag == 0) break;  // a full sweep without a rotation: converged (uniform: read after the barrier)
+    DSS_SYNC();
   }
-  // Ritz values and descending rank
-  for (int c = DSS_WAVE; c < m; c += DSS_NWAVES) {
-    double s = 0.;
-    for (int i = DSS_LANE; i < m; i += DSS_LANES) { const double x = A[(size_t)c * m + i]; s += x * x; }
-    s = DSS_WAVE_SUM(s);
-    if (DSS_LANE == 0) sm->theta[c] = sqrt(s) - EIGS_SHIFT;
-  }
+  for (int c = DSS_TID; c < m; c += DSS_NT) sm->theta[c] = A[(size_t)c * m + c];
   DSS_SYNC();
   for (int c = DSS_TID; c < m; c += DSS_NT) {
     int rank = 0;
@@ -262,6 +274,35 @@ DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm) {
     sm->perm[rank] = c;
   }
   DSS_SYNC();
+}
+
+// Rayleigh-Ritz on the projected matrix T (m x m): diagonal alpha, arrow column l (after a restart),
+// off-diagonal beta[j] = T[j][j+1] for j >= l.  Returns the number of the K wanted Ritz pairs whose residual
+// |beta_last * z_{m-1,i}| exceeds tol * max(|theta_i|, 1e-3).  Leaves Vr / sm->theta / sm->perm set.
+DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double beta_last, float tol, EigsSmall* sm) {
+  for (int idx = DSS_TID; idx < m * m; idx += DSS_NT) {
+    const int c = idx / m, r = idx - c * m;
+    double t = 0.;
+    if (r == c) t = sm->alpha[r];
+    else {
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      if (hi == l && lo < l) t = sm->arrow[lo];
+      else if (hi == lo + 1 && lo >= l) t = sm->beta[lo];
+    }
+    A[idx] = t;
+    Vr[idx] = r == c ? 1.0 : 0.0;
+  }
+  DSS_SYNC();
+  jacobi_eig(A, Vr, m, sm);
+  int nbad = 0;
+  for (int i = 0; i < K; ++i) {
+    if (i >= m) { ++nbad; continue; }
+    const int c = sm->perm[i];
+    const double res = fabs(beta_last * Vr[(size_t)c * m + (m - 1)]);
+    const double th = fabs(sm->theta[c]);
+    if (res > (double)tol * (th > 1e-3 ? th : 1e-3)) ++nbad;
+  }
+  return nbad;
 }
 
 // The whole eigen stage for ONE image (called by every thread of the owning workgroup).
@@ -312,7 +353,7 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
   int restart = 0;
   for (;; ++restart) {
     // ---- extend the Krylov basis from l to m --------------------------------------------------------
-    bool breakdown = false;
+    bool breakdown = false, early = false;
     for (int j = l; j < mmax; ++j) {
       const float* vj = Va + (size_t)j * ldv;
       for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? dis[e] * vj[e] : 0.0f;
@@ -351,30 +392,15 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
       }
       m = j + 1;
       DSS_SYNC();
-    }
-    // ---- Rayleigh-Ritz on T (m x m): diag alpha, arrow column l, off-diagonal beta ---------------------
-    for (int idx = DSS_TID; idx < m * m; idx += DSS_NT) {
-      const int c = idx / m, r = idx - c * m;
-      double t = 0.;
-      if (r == c) t = sm->alpha[r] + EIGS_SHIFT;
-      else {
-        const int lo = r < c ? r : c, hi = r < c ? c : r;
-        if (hi == l && lo < l) t = sm->arrow[lo];
-        else if (hi == lo + 1 && lo >= l) t = sm->beta[lo];
+      // mid-cycle convergence check every 2 steps: a converged image stops streaming W at once
+      if (m < mmax && m >= K + 3 && m > l + 1 && ((m - l) & 1) == 0) {
+        if (rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm) == 0) { early = true; break; }
+        DSS_SYNC();
       }
-      A[idx] = t;
-      Vr[idx] = r == c ? 1.0 : 0.0;
     }
-    DSS_SYNC();
-    jacobi_eig(A, Vr, m, sm);
-    // residual norms of the K wanted Ritz pairs: |beta_m * z_{m-1,i}|
+    // ---- Rayleigh-Ritz on the full basis (skipped when a mid-cycle check already converged) -----------------
     int nbad = 0;
-    for (int i = 0; i < K && i < m; ++i) {
-      const int c = sm->perm[i];
-      const double res = fabs(beta_last * Vr[(size_t)c * m + (m - 1)]);
-      const double th = fabs(sm->theta[c]);
-      if (res > (double)P.tol * (th > 1e-3 ? th : 1e-3)) ++nbad;
-    }
+    if (!early) nbad = rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm);
     converged = (nbad == 0);
     if (converged || breakdown || restart >= P.max_restarts) break;
     // ---- thick restart: keep the best `keep` Ritz vectors -----------------------------------------------

@@ -42,7 +42,7 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DSS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = local_device()
@@ -79,8 +79,11 @@ def gather_to_root(packed: torch.Tensor, n_total: int):
         return packed[order]
     width = packed.shape[1]
     n_max = (n_total + world - 1) // world
-    padded = torch.full((n_max, width), -1.0, dtype=torch.float32, device=packed.device)
-    padded[: packed.shape[0]] = packed
+    dev = packed.device
+    if dist.get_backend() == "gloo":
+        dev = torch.device("cpu")  # gloo gathers host tensors (CPU tests, single-GPU debugging)
+    padded = torch.full((n_max, width), -1.0, dtype=torch.float32, device=dev)
+    padded[: packed.shape[0]] = packed.to(dev)
     out = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
     dist.gather(padded, out, dst=0)
     if rank != 0:

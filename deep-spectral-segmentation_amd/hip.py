@@ -170,14 +170,14 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[t
     b, t, c3 = qkv.shape
     assert c3 == 3 * heads * 64, "head dim must be 64"
     need = attention_workspace_bytes(b, t, heads)
-    if workspace is None or workspace.numel() * workspace.element_size() < need:
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    wptr, wbytes = (0, 0) if not need else (_dev(workspace, "workspace"), workspace.numel() * workspace.element_size())
     if out is None:
         out = torch.empty((b, t, heads * 64), dtype=qkv.dtype, device=qkv.device)
     with _timed("attention", b=b, t=t, heads=heads):
         _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), b, t, heads, float(scale),
-                                                dtype_code(qkv.dtype), _dev(workspace, "workspace"),
-                                                workspace.numel() * workspace.element_size(), _stream()),
+                                                dtype_code(qkv.dtype), wptr, wbytes, _stream()),
                "dss_attention_fwd")
     return out
 

@@ -19,6 +19,7 @@ loads unchanged.
 from __future__ import annotations
 
 import math
+from pathlib import Path
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -28,6 +29,36 @@ from . import hip
 from .synthetic import VIT_CONFIGS
 
 LN_EPS = 1e-6
+_TUNING_FILE = Path(__file__).resolve().parent / "tuning" / "tunableop_gfx950.csv"
+_gemm_tuning_ready = False
+
+
+def setup_gemm_tuning(tune_new_shapes: Optional[bool] = None) -> None:
+    """The dense Linear layers are hipBLASLt GEMMs issued through PyTorch.  PyTorch's TunableOp picks, per GEMM
+    shape, the fastest hipBLASLt/rocBLAS solution; the table measured on MI355X for the bench shapes ships in
+    ``tuning/tunableop_gfx950.csv`` (+5 % end to end over the default heuristic).  Shapes not in the table use
+    the default heuristic unless ``tune_new_shapes`` (or ``DSS_GEMM_TUNE=1``) asks for on-line tuning
+    (~3 s per new shape, once)."""
+    global _gemm_tuning_ready
+    import os
+
+    tun = torch.cuda.tunable
+    if not _gemm_tuning_ready:
+        if os.environ.get("DSS_GEMM_TUNE", "") == "off":
+            return
+        tun.enable(True)
+        if hasattr(tun, "write_file_on_exit"):
+            tun.write_file_on_exit(False)  # never rewrite the shipped table behind the user's back
+        tun.set_max_tuning_duration(15)
+        if _TUNING_FILE.is_file():
+            try:
+                tun.read_file(str(_TUNING_FILE))
+            except Exception as e:  # a table from another ROCm build is ignored, not fatal
+                print(f"[dss] ignoring GEMM tuning table {_TUNING_FILE.name}: {e}")
+        _gemm_tuning_ready = True
+    if tune_new_shapes is None:
+        tune_new_shapes = os.environ.get("DSS_GEMM_TUNE", "") == "1"
+    tun.tuning_enable(bool(tune_new_shapes))
 
 
 def interpolate_pos_encoding(pos_embed: torch.Tensor, patch: int, h: int, w: int) -> torch.Tensor:
@@ -101,6 +132,7 @@ class DinoViT:
         self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._attn_ws: Optional[torch.Tensor] = None
         hip.load_library()  # fail now, not mid-run, if the kernels are missing
+        setup_gemm_tuning()
 
     # ------------------------------------------------------------------------------------------
     def _pos(self, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -112,8 +144,10 @@ class DinoViT:
             self._pos_cache[key] = (cls_row.contiguous(), pe[0, 1:].to(self.device).contiguous())
         return self._pos_cache[key]
 
-    def _attn_workspace(self, b: int, t: int) -> torch.Tensor:
+    def _attn_workspace(self, b: int, t: int) -> Optional[torch.Tensor]:
         need = hip.attention_workspace_bytes(b, t, self.num_heads)
+        if need == 0:
+            return None
         if self._attn_ws is None or self._attn_ws.numel() < need:
             self._attn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._attn_ws

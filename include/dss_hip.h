@@ -68,7 +68,8 @@ int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, const float
  * qkv: [B, T, 3, heads, 64] in `dtype` (the qkv Linear's output, untouched);
  * out: [B, T, heads*64] in `dtype`  = softmax(q k^T * scale) v, heads re-interleaved as the
  * reference's `.transpose(1, 2).reshape(B, T, C)`.  fp32 accumulation and softmax statistics.
- * workspace: dss_attention_workspace_bytes(B, T, heads) bytes (packed Q/K/V^T panels). */
+ * workspace: dss_attention_workspace_bytes(B, T, heads) bytes - 0 (pass NULL) for the default LDS-staged
+ * kernel, which reads qkv in place; packed Q/K/V^T panels for the DSS_ATTENTION_IMPL=1 variant. */
 size_t dss_attention_workspace_bytes(int B, int T, int heads);
 int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
