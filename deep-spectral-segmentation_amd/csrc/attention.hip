@@ -222,35 +222,62 @@ __device__ __forceinline__ typename vec8<T>::type lds_read_tr_pair(const T* p_lo
 static constexpr int KLD = 72;   // halves per K row in LDS (144 B)
 static constexpr int VLD = 96;   // halves per V row in LDS (192 B)
 
+// Cross-half (lane ^ 32) exchange on the VALU (v_permlane32_swap), no LDS round trip: returns, in every lane,
+// max(x[lane & 31], x[32 + (lane & 31)]).
+// NOTE (hipcc / ROCm 7.2 front-end bug): __builtin_bit_cast(float, r[1]) applied directly to an element of the
+// builtin's 2-vector result reads element 0 (seen in the -O0 IR: both loads use the vector's base address), which
+// silently turned max(r0, r1) into r0 and r0 + r1 into 2*r0.  Copy the elements into scalars first.
+__device__ __forceinline__ float half_pair_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned lo = r[0], hi = r[1];
+  return fmaxf(__uint_as_float(lo), __uint_as_float(hi));
+}
+__device__ __forceinline__ float half_pair_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned lo = r[0], hi = r[1];
+  return __uint_as_float(lo) + __uint_as_float(hi);
+}
+
+// Online-softmax update for one 32-query block on a 32-key score tile (raw q.k scores in s).
+//   m   : running max in RAW score units (shared by both half-waves of a query)
+//   mc  : m * c  (c = scale * log2 e), so p = exp2(fma(s, c, -mc)) is one FMA + one v_exp per score
+//   l   : THIS LANE's partial row sum (its half of the keys); the two halves are added once, in the epilogue
+// The O accumulators are rescaled only when some query's max grew by more than RESCALE_THR (in log2 units):
+// until then p <= 2^RESCALE_THR, harmless for f16/bf16 operands and the f32 accumulators.  The decision is
+// wave-uniform (ballot), taken BEFORE this tile's probabilities exist, so every p, l and O stays consistent.
+static constexpr float RESCALE_THR = 6.0f;
 template <class T>
-__device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& lsum, f32x16& o0, f32x16& o1,
-                                              typename vec8<T>::type& pb0, typename vec8<T>::type& pb1,
-                                              float scale_log2, bool tail, int key0, int hh, int Tn) {
-  float mx = -1.0e30f;
+__device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& mc, float& l, f32x16& o0, f32x16& o1,
+                                              typename vec8<T>::type& pb0, typename vec8<T>::type& pb1, float c,
+                                              bool tail, int key0, int hh, int Tn) {
+  if (tail) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v = s[r] * scale_log2;
-    if (tail) {
+    for (int r = 0; r < 16; ++r) {
       const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (key >= Tn) v = -INFINITY;
+      if (key >= Tn) s[r] = -INFINITY;
     }
-    s[r] = v;
-    mx = fmaxf(mx, v);
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float m_new = fmaxf(m, mx);
-  const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+  float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+  mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+  mx = half_pair_max(mx);
+  if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_THR) != 0) {  // wave-uniform
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);       // m = -1e30 initially -> alpha = 0
+    m = m_new;
+    mc = m_new * c;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+  }
   float rs = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+    s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -mc));
     rs += s[r];
   }
-  rs += __shfl_xor(rs, 32, 64);
-  lsum = lsum * alpha + rs;
-  m = m_new;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+  l += rs;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     pb0[e] = from_f32<T>(s[e]);
@@ -332,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
   f32x16 oa0, oa1, ob0, ob1;   // O^T accumulators: query block a/b x dh block 0/1
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
-  float ma = -1.0e30f, la = 0.f, mb = -1.0e30f, lb = 0.f;
+  float ma = -1.0e30f, mca = -1.0e30f * scale_log2, la = 0.f, mb = -1.0e30f, mcb = -1.0e30f * scale_log2, lb = 0.f;
 
   const int nkt = (Tn + 63) / 64;
   stage_load(0);
@@ -361,8 +388,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
           }
           const bool tail = key0 + 32 > Tn;
           V8 pa0, pa1, pb0, pb1;
-          softmax_block<T>(sa, ma, la, oa0, oa1, pa0, pa1, scale_log2, tail, key0, hh, Tn);
-          softmax_block<T>(sb, mb, lb, ob0, ob1, pb0, pb1, scale_log2, tail, key0, hh, Tn);
+          softmax_block<T>(sa, ma, mca, la, oa0, oa1, pa0, pa1, scale_log2, tail, key0, hh, Tn);
+          softmax_block<T>(sb, mb, mcb, lb, ob0, ob1, pb0, pb1, scale_log2, tail, key0, hh, Tn);
           const T* vbase = &Vs[buf][(half * 32 + tr_row) * VLD + tr_col];
           {  // t = 0 (keys 0..15 of the block), dh blocks 0 and 1
             const V8 v0 = lds_read_tr_pair<T>(vbase, vbase + 8 * VLD);
@@ -404,8 +431,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
       *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = c;
     }
   };
-  store_q(q0 + li, oa0, oa1, la);
-  store_q(q0 + 32 + li, ob0, ob1, lb);
+  store_q(q0 + li, oa0, oa1, half_pair_sum(la));       // the two half-waves hold disjoint keys of each query
+  store_q(q0 + 32 + li, ob0, ob1, half_pair_sum(lb));
 }
 
 template <class T>
