@@ -71,7 +71,7 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
         if name == "laplacian_eigs":
             n = metas[0]["n"]
             passes = [float(m["info"].abs().sum().item()) for m in metas]
-            byts = np.mean(passes) * 4.0 * n * n     # 4*N^2 algorithmic bytes per pass over W
+            byts = np.mean(passes) * 4.0 * n * (n + 1) / 2   # symmetric W: 4*N(N+1)/2 algorithmic bytes per pass
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          passes_per_image=float(np.sum(passes) / sum(m["b"] for m in metas)))
         elif name == "attention":
@@ -80,7 +80,7 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s")
         elif name == "affinity":
             m = metas[0]
-            flops = 2.0 * m["n"] ** 2 * m["d"] * m["b"]
+            flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle only: N(N+1)/2 dots of 2D flop
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])

@@ -18,6 +18,7 @@
 // D: register r of lane l is D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].  The k index is a dummy: lane half hh
 // feeds feature columns d0+4*hh+s to MFMA number s for both operands.
 #include "common.h"
+#include "eigs_core.h"
 
 namespace dss {
 
@@ -57,22 +58,31 @@ static constexpr int GB = 128;  // block tile (rows and cols)
 static constexpr int GK = 32;   // feature columns per LDS stage
 static constexpr int GLD = GK + 4;
 
+// Symmetric output: only block tiles with J0 >= I0 are computed (1-D grid over the upper block triangle) and each
+// wave's 64x64 quadrant is written as ONE packed storage tile (eigs_core.h: wsym_*), so the Gram FLOPs and the
+// bytes the eigensolver later streams are both halved.  Quadrants below the diagonal are skipped.
 __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict__ feats, float* __restrict__ W,
-                                                        int N, int D, int ldw, int relu) {
+                                                        int N, int D, int ldw, int relu, size_t w_stride) {
   __shared__ __attribute__((aligned(16))) float As[GB][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GB][GLD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int I0 = blockIdx.y * GB, J0 = blockIdx.x * GB;
+  const int nt = ldw / 64, nbk = (nt + 1) / 2;
+  int bi = 0, rem = blockIdx.x;                     // upper-triangular block index -> (bi, bj), bj >= bi
+  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
+  const int bj = bi + rem;
+  const int I0 = bi * GB, J0 = bj * GB;
   const float* F = feats + (long)blockIdx.z * N * D;
-  float* Wb = W + (long)blockIdx.z * N * ldw;
+  float* Wb = W + blockIdx.z * w_stride;
 
-  // which of this wave's four 32x32 sub-tiles intersect the matrix (wave-uniform)
+  // this wave's 64x64 quadrant = storage tile (ti, tj); active only if inside the matrix and on/above the diagonal
+  const int ti = 2 * bi + wr, tj = 2 * bj + wc;
+  const bool quad = ti < nt && tj < nt && tj >= ti;
   const int ri0 = I0 + wr * 64, cj0 = J0 + wc * 64;
-  const bool act_r0 = ri0 < N, act_r1 = ri0 + 32 < N;
-  const bool act_c0 = cj0 < ldw, act_c1 = cj0 + 32 < ldw;
+  const bool act_r0 = quad && ri0 < N, act_r1 = quad && ri0 + 32 < N;
+  const bool act_c0 = quad && cj0 < N, act_c1 = quad && cj0 + 32 < N;
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -108,25 +118,26 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
     __syncthreads();
   }
 
-  // epilogue: relu, zero the pad columns [N, ldw), coalesced 128-byte row segments per half-wave
-  auto store_tile = [&](const f32x16& acc, int rbase, int cbase) {
-    const int col = cbase + li;
-    if (col >= ldw) return;
+  // epilogue: relu; rows/columns >= N are written as 0 (the matvec relies on it); each half-wave stores 32
+  // consecutive floats (128 B) of a tile row.  The whole 64x64 storage tile is always written.
+  if (!quad) return;
+  float* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
+    const int col = cj0 + csub + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (row < N) {
-        float v = acc[r];
-        if (relu) v = fmaxf(v, 0.f);
-        if (col >= N) v = 0.f;
-        Wb[(long)row * ldw + col] = v;
-      }
+      const int lr = rsub + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int row = ri0 + lr;
+      float v = computed ? acc[r] : 0.f;
+      if (relu) v = fmaxf(v, 0.f);
+      if (row >= N || col >= N) v = 0.f;
+      tile[lr * 64 + csub + li] = v;
     }
   };
-  if (act_r0 && act_c0) store_tile(acc00, ri0, cj0);
-  if (act_r0 && act_c1) store_tile(acc01, ri0, cj0 + 32);
-  if (act_r1 && act_c0) store_tile(acc10, ri0 + 32, cj0);
-  if (act_r1 && act_c1) store_tile(acc11, ri0 + 32, cj0 + 32);
+  store_tile(acc00, 0, 0, act_r0 && act_c0);
+  store_tile(acc01, 0, 32, act_r0 && act_c1);
+  store_tile(acc10, 32, 0, act_r1 && act_c0);
+  store_tile(acc11, 32, 32, act_r1 && act_c1);
 }
 
 }  // namespace dss
@@ -143,6 +154,7 @@ extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, flo
 }
 
 extern "C" int dss_affinity_ld(int N) { return N > 0 ? dss::round_up(N, 64) : 0; }
+extern "C" size_t dss_affinity_elems(int N) { return N > 0 ? dss::wsym_floats(dss_affinity_ld(N)) : 0; }
 
 extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
                             void* stream) {
@@ -151,9 +163,9 @@ extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, i
   DSS_REQUIRE(D % dss::GK == 0, "dss_affinity: feature dim must be a multiple of %d (got %d)", dss::GK, D);
   DSS_REQUIRE(B <= 65535, "dss_affinity: B must be <= 65535");
   const int ldw = dss_affinity_ld(N);
-  const int nb = dss::ceil_div(ldw, dss::GB);
-  hipLaunchKernelGGL(dss::gram_relu_kernel, dim3(nb, dss::ceil_div(N, dss::GB), B), dim3(256), 0,
-                     (hipStream_t)stream, feats, W, N, D, ldw, threshold_at_zero ? 1 : 0);
+  const int nbk = (ldw / 64 + 1) / 2;
+  hipLaunchKernelGGL(dss::gram_relu_kernel, dim3(nbk * (nbk + 1) / 2, 1, B), dim3(256), 0, (hipStream_t)stream,
+                     feats, W, N, D, ldw, threshold_at_zero ? 1 : 0, dss_affinity_elems(N));
   DSS_CHECK_LAUNCH("gram_relu");
   return DSS_OK;
 }

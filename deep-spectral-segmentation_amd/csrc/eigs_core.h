@@ -83,6 +83,15 @@ DSS_HD inline EigsLds eigs_lds_layout(int ld, int ncv) {
   L.total = o;
   return L;
 }
+// ---- packed symmetric storage of W -------------------------------------------------------------------------
+// W is symmetric, so only its upper-triangular 64x64 tiles are stored and streamed: with nt = ld/64 tile rows,
+// tile (I, J), J >= I, is the t-th 4096-float block, t = I*nt - I*(I-1)/2 + (J - I), row-major inside the tile.
+// Diagonal tiles are stored in full.  Rows/columns >= N hold zeros.  N = 900: 120 tiles (1.97 MB) instead of 3.46 MB.
+static constexpr int WT = 64;
+DSS_HD inline int wsym_tiles(int nt) { return nt * (nt + 1) / 2; }
+DSS_HD inline size_t wsym_floats(int ld) { return (size_t)wsym_tiles(ld / WT) * WT * WT; }
+DSS_HD inline int wsym_row_start(int I, int nt) { return I * nt - I * (I - 1) / 2; }
+
 // global workspace per image (floats): two basis buffers [(ncv+1) x ld] + dis[ld]
 DSS_HD inline size_t eigs_ws_floats_per_image(int ld, int ncv) { return (size_t)2 * (ncv + 1) * ld + ld; }
 
@@ -134,51 +143,112 @@ DSS_DEV float hash_unit(uint32_t e) {  // deterministic start vector entry in [-
   return (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
 }
 
-// ws[r] = (scale ? dis[r] : 1) * sum_c W[r][c] * xs[c]     - the one pass over W per Lanczos step.
-DSS_DEV void matvec_rows(const float* __restrict__ W, int N, int ld, const float* xs, float* ws,
-                         const float* dis, bool scale) {
+// ws = (scale ? D^-1/2 : I) * W * xs  from the packed upper-triangular tiles: the ONE pass over W per Lanczos
+// step.  Every stored tile A = W[I-block, J-block] is read once and contributes A x_J to y_I and, when I != J,
+// A^T x_I to y_J.  One wave owns one 16-KiB tile at a time (16 x 16-byte loads per lane, perfectly contiguous);
+// the 64 row sums and 64 column sums are reduced inside the wave by halving butterflies (15 + 3 exchanges, after
+// which every lane owns exactly one finished row sum and one column sum) and added to the LDS accumulator with one
+// ds_add_f32 per lane.  (Floating-point LDS atomics: the accumulation order across waves is not fixed, so results
+// are reproducible to rounding, not bitwise.)   xs must be zero beyond N.  Barriers inside.
+DSS_DEV void matvec_sym(const float* __restrict__ Wp, int N, int ld, const float* xs, float* ws, const float* dis,
+                        bool scale) {
+  const int nt = ld / WT;
+  for (int e = DSS_TID; e < ld; e += DSS_NT) ws[e] = 0.f;
+  DSS_SYNC();
 #ifdef DSS_HOST_EMUL
-  for (int r = 0; r < N; ++r) {
-    float acc = 0.f;
-    for (int c = 0; c < ld; ++c) acc += W[(size_t)r * ld + c] * xs[c];
-    ws[r] = scale ? acc * dis[r] : acc;
-  }
-#else
-  // One wave owns 4 consecutive rows at a time: 4 x 16-byte global loads per lane share one 16-byte LDS
-  // read of x; 64 lanes x float4 = 1 KiB of each row per instruction (fully coalesced).
-  const int lane = DSS_LANE;
-  const int nvec = ld >> 2;
-  const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
-  for (int r0 = DSS_WAVE * 4; r0 < N; r0 += DSS_NWAVES * 4) {
-    const int r1 = r0 + 1 < N ? r0 + 1 : N - 1, r2 = r0 + 2 < N ? r0 + 2 : N - 1,
-              r3 = r0 + 3 < N ? r0 + 3 : N - 1;
-    const f32x4* w0 = reinterpret_cast<const f32x4*>(W + (size_t)r0 * ld);
-    const f32x4* w1 = reinterpret_cast<const f32x4*>(W + (size_t)r1 * ld);
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(W + (size_t)r2 * ld);
-    const f32x4* w3 = reinterpret_cast<const f32x4*>(W + (size_t)r3 * ld);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 2
-    for (int c = lane; c < nvec; c += 64) {
-      const f32x4 x = xs4[c];
-      const f32x4 p0 = __builtin_nontemporal_load(w0 + c);
-      const f32x4 p1 = __builtin_nontemporal_load(w1 + c);
-      const f32x4 p2 = __builtin_nontemporal_load(w2 + c);
-      const f32x4 p3 = __builtin_nontemporal_load(w3 + c);
-      a0 += (p0[0] * x[0] + p0[1] * x[1]) + (p0[2] * x[2] + p0[3] * x[3]);
-      a1 += (p1[0] * x[0] + p1[1] * x[1]) + (p1[2] * x[2] + p1[3] * x[3]);
-      a2 += (p2[0] * x[0] + p2[1] * x[1]) + (p2[2] * x[2] + p2[3] * x[3]);
-      a3 += (p3[0] * x[0] + p3[1] * x[1]) + (p3[2] * x[2] + p3[3] * x[3]);
-    }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    if (lane < 4) {
-      const int r = r0 + lane;
-      if (r < N) {
-        float a = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
-        ws[r] = scale ? a * dis[r] : a;
+  for (int I = 0; I < nt; ++I)
+    for (int J = I; J < nt; ++J) {
+      const float* A = Wp + (size_t)(wsym_row_start(I, nt) + (J - I)) * WT * WT;
+      for (int r = 0; r < WT; ++r) {
+        float acc = 0.f;
+        for (int c = 0; c < WT; ++c) acc += A[r * WT + c] * xs[J * WT + c];
+        ws[I * WT + r] += acc;
       }
+      if (I != J)
+        for (int c = 0; c < WT; ++c) {
+          float acc = 0.f;
+          for (int r = 0; r < WT; ++r) acc += A[r * WT + c] * xs[I * WT + r];
+          ws[J * WT + c] += acc;
+        }
+    }
+#else
+  const int lane = DSS_LANE;
+  const int g = lane >> 4, q = lane & 15;         // lane -> rows 4k + g (k = 0..15), columns 4q .. 4q+3
+  const int ntiles = wsym_tiles(nt);
+  int I = 0, row_start = 0;                        // tile row of the current tile index (advanced incrementally)
+  for (int t = DSS_WAVE; t < ntiles; t += DSS_NWAVES) {
+    while (t >= row_start + (nt - I)) { row_start += nt - I; ++I; }
+    const int J = I + (t - row_start);
+    const f32x4* A4 = reinterpret_cast<const f32x4*>(Wp + (size_t)t * WT * WT);
+    f32x4 a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = __builtin_nontemporal_load(A4 + k * 64 + lane);
+    const f32x4 xj = *reinterpret_cast<const f32x4*>(xs + J * WT + 4 * q);
+    float rp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rp[k] = (a[k][0] * xj[0] + a[k][1] * xj[1]) + (a[k][2] * xj[2] + a[k][3] * xj[3]);
+    // halving butterfly over the 16 lanes that share a row group: after step with mask w, a lane keeps the rows
+    // whose k has bit (w) equal to its own lane bit
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool up = (q & 8) != 0;
+      const float send = up ? rp[k] : rp[k + 8];
+      const float keep = up ? rp[k + 8] : rp[k];
+      rp[k] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool up = (q & 4) != 0;
+      const float send = up ? rp[k] : rp[k + 4];
+      const float keep = up ? rp[k + 4] : rp[k];
+      rp[k] = keep + __shfl_xor(send, 4, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool up = (q & 2) != 0;
+      const float send = up ? rp[k] : rp[k + 2];
+      const float keep = up ? rp[k + 2] : rp[k];
+      rp[k] = keep + __shfl_xor(send, 2, 64);
+    }
+    {
+      const bool up = (q & 1) != 0;
+      const float send = up ? rp[0] : rp[1];
+      const float keep = up ? rp[1] : rp[0];
+      rp[0] = keep + __shfl_xor(send, 1, 64);
+    }
+    // this lane now owns row k = q (bit-for-bit: bit 3 of k from lane bit 3, ...), i.e. tile row 4*q + g
+    atomicAdd(&ws[I * WT + 4 * q + g], rp[0]);
+    if (I != J) {
+      f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float xi = xs[I * WT + 4 * k + g];
+        cp[0] += a[k][0] * xi; cp[1] += a[k][1] * xi; cp[2] += a[k][2] * xi; cp[3] += a[k][3] * xi;
+      }
+      // reduce over the 4 row groups (lane bits 4,5) while halving 4 -> 2 -> 1 columns per lane
+      float c0, c1;
+      {
+        const bool up = (g & 1) != 0;   // lane bit 4
+        const float s0 = up ? cp[0] : cp[2], s1 = up ? cp[1] : cp[3];
+        const float k0 = up ? cp[2] : cp[0], k1 = up ? cp[3] : cp[1];
+        c0 = k0 + __shfl_xor(s0, 16, 64);
+        c1 = k1 + __shfl_xor(s1, 16, 64);
+      }
+      {
+        const bool up = (g & 2) != 0;   // lane bit 5
+        const float send = up ? c0 : c1;
+        const float keep = up ? c1 : c0;
+        c0 = keep + __shfl_xor(send, 32, 64);
+      }
+      // owned column: 4*q + 2*(g & 1) + (g >> 1)
+      atomicAdd(&ws[J * WT + 4 * q + 2 * (g & 1) + (g >> 1)], c0);
     }
   }
 #endif
+  DSS_SYNC();
+  if (scale)
+    for (int e = DSS_TID; e < N; e += DSS_NT) ws[e] *= dis[e];
+  DSS_SYNC();
 }
 
 // coef[i] = V[i] . ws  for i in [0, nvec)  (wave per basis vector, lanes strided over elements)
@@ -306,7 +376,7 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
 }
 
 // The whole eigen stage for ONE image (called by every thread of the owning workgroup).
-//   W          [N, ld] f32, symmetric, non-negative, pad columns zero
+//   W          packed upper-triangular 64x64 tiles of the symmetric non-negative affinity (wsym_floats(ld) floats)
 //   gws        global workspace of eigs_ws_floats_per_image(ld, ncv) floats
 //   lds        LDS block of eigs_lds_layout(ld, ncv).total bytes (16-byte aligned)
 //   eigenvalues[K], eigenvectors[K, N] outputs; *info = +passes (converged) / -passes (budget exhausted)
@@ -328,9 +398,8 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
   // ---- degree: d = W 1 ; clamp ; dis = d^-1/2 -------------------------------------------------
   for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? 1.0f : 0.0f;
   DSS_SYNC();
-  matvec_rows(W, N, ld, xs, ws, nullptr, false);
+  matvec_sym(W, N, ld, xs, ws, nullptr, false);
   ++passes;
-  DSS_SYNC();
   for (int e = DSS_TID; e < ld; e += DSS_NT) {
     float d = e < N ? ws[e] : 1.0f;
     if (d < 1e-12f) d = 1.0f;
@@ -358,9 +427,8 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
       const float* vj = Va + (size_t)j * ldv;
       for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? dis[e] * vj[e] : 0.0f;
       DSS_SYNC();
-      matvec_rows(W, N, ld, xs, ws, dis, true);
+      matvec_sym(W, N, ld, xs, ws, dis, true);
       ++passes;
-      DSS_SYNC();
       // classical Gram-Schmidt, two passes (full reorthogonalisation against V[0..j])
       basis_dots(Va, ldv, j + 1, ws, N, sm->coef);
       DSS_SYNC();

@@ -152,9 +152,10 @@ def parallel_process(inputs: Iterable, fn: Callable, multiprocessing: int = 0):
 
 
 def get_diagonal(W: torch.Tensor, n: Optional[int] = None, threshold: float = 1e-12) -> torch.Tensor:
-    """Degree vector of an affinity matrix held on the GPU (``[N, ld]`` or ``[N, N]``): row sums with the
-    reference's clamp.  Diagnostic helper - the eigensolver computes the same thing internally."""
+    """Degree vector of a DENSE affinity matrix held on the GPU (``[N, N]`` or the ``[ld, ld]`` produced by
+    ``hip.affinity_to_dense``): row sums with the reference's clamp.  Diagnostic helper - the eigensolver
+    computes the same thing internally from the packed tiles."""
     n = W.shape[0] if n is None else n
-    d = W[:, :n].sum(dim=1)
+    d = W[:n, :n].sum(dim=1)
     d[d < threshold] = 1.0
     return d

@@ -33,6 +33,7 @@ SYMBOLS = {
                                   c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
+    "dss_affinity_elems": (c_size_t, [c_int]),
     "dss_affinity": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dss_laplacian_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
@@ -196,11 +197,34 @@ def affinity_ld(n: int) -> int:
     return int(load_library().dss_affinity_ld(n))
 
 
+def affinity_elems(n: int) -> int:
+    return int(load_library().dss_affinity_elems(n))
+
+
+def affinity_to_dense(wp: torch.Tensor, n: int) -> torch.Tensor:
+    """Unpack ``[B, affinity_elems(N)]`` (upper-triangular 64x64 tiles) into dense symmetric ``[B, ld, ld]``
+    (diagnostics / tests; the product never materialises the dense matrix)."""
+    ld = affinity_ld(n)
+    nt = ld // 64
+    b = wp.shape[0]
+    tiles = wp.reshape(b, -1, 64, 64)
+    dense = torch.zeros((b, ld, ld), dtype=wp.dtype, device=wp.device)
+    t = 0
+    for i in range(nt):
+        for j in range(i, nt):
+            dense[:, 64 * i:64 * i + 64, 64 * j:64 * j + 64] = tiles[:, t]
+            if j != i:
+                dense[:, 64 * j:64 * j + 64, 64 * i:64 * i + 64] = tiles[:, t].transpose(1, 2)
+            t += 1
+    return dense
+
+
 def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tensor:
-    """f32 ``[B, N, D]`` -> f32 ``[B, N, ld]`` with ``W[b, i, j] = relu(<f_i, f_j>)`` for j < N, 0 beyond."""
+    """f32 ``[B, N, D]`` -> f32 ``[B, affinity_elems(N)]``: ``W = relu(F F^T)`` as packed upper-triangular 64x64
+    tiles (layout: include/dss_hip.h)."""
     assert feats.dtype == torch.float32 and feats.dim() == 3
     b, n, d = feats.shape
-    w = torch.empty((b, n, affinity_ld(n)), dtype=torch.float32, device=feats.device)
+    w = torch.empty((b, affinity_elems(n)), dtype=torch.float32, device=feats.device)
     with _timed("affinity", b=b, n=n, d=d):
         _check(load_library().dss_affinity(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(threshold_at_zero),
                                            _stream()), "dss_affinity")
@@ -209,8 +233,8 @@ def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tenso
 
 def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0.0, max_restarts: int = 0,
                    workspace: Optional[torch.Tensor] = None):
-    """``W`` ``[B, N, ld]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]`` int32)."""
-    assert w.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == n and w.shape[2] == affinity_ld(n)
+    """packed ``W`` ``[B, affinity_elems(N)]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]``)."""
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == affinity_elems(n)
     b = w.shape[0]
     lib = load_library()
     need = int(lib.dss_eigs_workspace_bytes(b, n, k, ncv))

@@ -38,7 +38,7 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     if not K < n:
         raise ValueError(f"need K < N (K={K}, N={n})")
     ld = hip.affinity_ld(n)
-    per_image = n * ld * 4 + 2 * 66 * ld * 4
+    per_image = hip.affinity_elems(n) * 4 + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
     evals, evecs, infos = [], [], []
     for s in range(0, b, chunk):

@@ -82,9 +82,13 @@ int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, voi
  * extract/extract.py:191-194  W = F F^T ; W = W * (W > 0)   (exact fp32 MFMA, fmaf-chain numerics).
  * `W / W.max()` (:194) is NOT applied: the generalized problem (D-W)v = lambda D v is invariant
  * under W -> cW; eigenvalues and eigenvectors are unchanged.
- * feats: [B, N, D] f32 (already normalised if wanted).  W: [B, N, ldw] f32, ldw = dss_affinity_ld(N)
- * (row stride padded to 64 floats; pad columns are written as 0). */
+ * feats: [B, N, D] f32 (already normalised if wanted).
+ * W is symmetric, so it is produced (and later streamed) as PACKED UPPER-TRIANGULAR 64x64 TILES: with
+ * ld = dss_affinity_ld(N) = N rounded up to 64 and nt = ld/64, tile (I, J), J >= I, is the t-th block of
+ * 4096 floats, t = I*nt - I*(I-1)/2 + (J-I), row-major inside the tile, diagonal tiles stored in full, entries
+ * with row or column >= N are 0.  Per image dss_affinity_elems(N) floats: W is [B, dss_affinity_elems(N)]. */
 int dss_affinity_ld(int N);
+size_t dss_affinity_elems(int N);
 int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
                  void* stream);
 
@@ -93,9 +97,10 @@ int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshol
  * extract/extract.py:227            eigsh(D - W, k=K, sigma=0, which='LM', M=D)
  * extract/extract.py:235-240        eigenvectors.T (f32 [K, N]) ; sign rule
  * Solved as the K LARGEST eigenpairs (mu, u) of S = D^-1/2 W D^-1/2 by thick-restart Lanczos
- * with full reorthogonalisation (one workgroup per image; W streamed once per Lanczos step);
+ * with full reorthogonalisation (one workgroup per image; the stored half of W streamed once per Lanczos step);
  * lambda = 1 - mu ascending, v = D^-1/2 u  (so v^T D v = 1, the reference's normalisation).
- * W: [B, N, ldw] f32 symmetric non-negative.  eigenvalues: [B, K] f32.  eigenvectors: [B, K, N] f32.
+ * W: [B, dss_affinity_elems(N)] f32, packed as dss_affinity writes it.  eigenvalues: [B, K] f32.
+ * eigenvectors: [B, K, N] f32.
  * info: [B] int32 - number of W passes (>0) if converged, -(passes) if the restart budget ran out
  * (outputs then hold the best available Ritz pairs).
  * ncv: Krylov dimension (0 = default max(2K+10, 20), capped at 64); tol: Ritz residual tolerance

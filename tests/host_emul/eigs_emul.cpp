@@ -10,6 +10,7 @@
 
 #include "../../deep-spectral-segmentation_amd/csrc/eigs_core.h"
 
+// W: packed upper-triangular 64x64 tiles (csrc/eigs_core.h wsym_*), wsym_floats(ld) floats per image.
 extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int K, float* eigenvalues,
                                        float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
                                        int max_restarts) {
@@ -25,7 +26,7 @@ extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int
   std::vector<float> gws(eigs_ws_floats_per_image(ld, ncv));
   for (int b = 0; b < B; ++b) {
     memset(lp, 0, L.total);
-    eigs_one_image(W + (size_t)b * N * ld, P, gws.data(), lp, eigenvalues + (size_t)b * K,
+    eigs_one_image(W + (size_t)b * wsym_floats(ld), P, gws.data(), lp, eigenvalues + (size_t)b * K,
                    eigenvectors + (size_t)b * K * N, info + b);
   }
   return 0;

@@ -135,16 +135,18 @@ def test_affinity_matches_fp64(b, n, d):
                                                                      None if int(n ** 0.5) ** 2 == n else (1, n))
                                        for i in range(b)]))
     fn = hip.normalize_rows(feats.to(DEV))
-    w = hip.affinity(fn).cpu()
+    wp = hip.affinity(fn)
     ld = hip.affinity_ld(n)
-    assert tuple(w.shape) == (b, n, ld) and ld % 64 == 0 and ld >= n
-    assert torch.equal(w[:, :, n:], torch.zeros(b, n, ld - n))  # pad columns are zero
+    nt = ld // 64
+    assert tuple(wp.shape) == (b, nt * (nt + 1) // 2 * 4096) and ld % 64 == 0 and ld >= n
+    w = hip.affinity_to_dense(wp, n).cpu()           # [b, ld, ld] from the packed upper-triangular tiles
+    assert torch.equal(w[:, :, n:], torch.zeros(b, ld, ld - n)) and torch.equal(w[:, n:, :], torch.zeros(b, ld - n, ld))
     x = F.normalize(feats.double(), dim=-1)
     ref = (x @ x.transpose(1, 2)).clamp_min(0)
-    assert (w[:, :, :n].double() - ref).abs().max().item() < 2e-6
-    assert torch.equal(w[:, :, :n], w[:, :, :n].transpose(1, 2))  # bit-symmetric (same fmaf chain both ways)
-    wneg = hip.affinity(fn, threshold_at_zero=False).cpu()
-    assert (wneg[:, :, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
+    assert (w[:, :n, :n].double() - ref).abs().max().item() < 2e-6
+    assert torch.equal(w, w.transpose(1, 2))         # diagonal tiles are stored in full and bit-symmetric
+    wneg = hip.affinity_to_dense(hip.affinity(fn, threshold_at_zero=False), n).cpu()
+    assert (wneg[:, :n, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
 
 
 # ----------------------------------------------------------------------------- eigen stage

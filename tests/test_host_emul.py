@@ -27,6 +27,16 @@ def emul(tmp_path_factory):
     return lib
 
 
+def pack_sym(w, ld):
+    """Dense [n, n] -> packed upper-triangular 64x64 tiles (include/dss_hip.h, dss_affinity)."""
+    n = w.shape[0]
+    nt = ld // 64
+    full = np.zeros((ld, ld), np.float32)
+    full[:n, :n] = w
+    tiles = [full[64 * i:64 * i + 64, 64 * j:64 * j + 64].reshape(-1) for i in range(nt) for j in range(i, nt)]
+    return np.ascontiguousarray(np.concatenate(tiles))
+
+
 def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60):
     x = feats / np.maximum(np.linalg.norm(feats, axis=1, keepdims=True), 1e-12)
     x = x.astype(np.float32)
@@ -34,8 +44,7 @@ def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60):
     w = w * (w > 0)
     n = w.shape[0]
     ld = (n + 63) // 64 * 64
-    wp = np.zeros((n, ld), np.float32)
-    wp[:, :n] = w
+    wp = pack_sym(w, ld)
     ncv = ncv or min(max(2 * K + 10, 20), 64, n)
     keep = keep or (ncv + K) // 2
     ev, vec, info = np.zeros(K, np.float32), np.zeros((K, n), np.float32), np.zeros(1, np.int32)
