@@ -8,8 +8,10 @@ Workload (BASELINE.json configs[1]): dino_vits16, 480x480 synthetic VOC-shaped i
 One STEP = one batch of ``--batch`` images (default 1024) already resident in HBM as uint8 HWC:
 transform+crop+im2col -> ViT (HIP LayerNorm/attention, hipBLASLt GEMMs) -> K features -> normalise ->
 affinity -> Lanczos eigenpairs -> [K, N] eigenvectors.  One ``B=1`` result per image, like the reference.
-Multi-GPU: every rank runs the same number of steps on its own images (weak scaling, no collective on the
-data path) and rank 0 gathers all eigenvectors once at the end (inside the timed region).
+Every rank streams its own results to pinned host memory asynchronously, step by step (that is where the CLI
+writes the per-image .pth files from).  Multi-GPU: every rank runs the same number of steps on its own images
+(weak scaling, no collective on the data path) and rank 0 gathers all eigenvectors once at the end, device to
+device (the single RCCL gather over xGMI) - all inside the timed region.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -168,25 +170,36 @@ def main():
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
-    results = []
+    results, packed_dev = [], []
+    width = a.K * n_patches + a.K + 1
+    host_out = torch.empty((a.steps, a.batch, width), dtype=torch.float32, pin_memory=True)  # this rank's results
+    copy_stream = torch.cuda.Stream(device=dev)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
         ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch)
-        results.append((ev, vec, info))
+        ids = (torch.arange(a.batch, device=dev) + s * a.batch) * world + rank   # global round-robin item ids
+        packed = distributed.pack_results(ids, ev, vec)
+        results.append(info)
+        packed_dev.append(packed)
+        # every rank streams ITS OWN [K, N] results to pinned host memory while the next step computes
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done)
+            host_out[s].copy_(packed, non_blocking=True)
     host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
-    ev = torch.cat([r[0] for r in results])
-    vec = torch.cat([r[1] for r in results])
-    ids = torch.arange(ev.shape[0], device=dev) * world + rank
-    gathered = distributed.gather_to_root(distributed.pack_results(ids, ev, vec), ev.shape[0] * world)
-    if gathered is not None:
-        gathered = gathered.cpu()  # D2H of every [K, N] result on rank 0
+    # the ONE collective of the run: gather every rank's packed rows on rank 0 (RCCL over xGMI when world > 1)
+    gathered = distributed.gather_to_root(torch.cat(packed_dev), a.steps * a.batch * world)
+    copy_stream.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    if gathered is not None:
+        assert gathered.shape[0] == a.steps * a.batch * world
     timers, hip.TIMERS = hip.TIMERS, None
     if world > 1:
         tdev = dev if torch.distributed.get_backend() != "gloo" else torch.device("cpu")
@@ -194,7 +207,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    info_all = torch.cat([r[2] for r in results])
+    info_all = torch.cat(results)
     n_unconverged = int((info_all <= 0).sum().item())
     if rank == 0:
         kern = summarize_timers(timers, n_patches, dim, depth)
