@@ -84,7 +84,7 @@ class DinoViT:
     """Inference-only DINO ViT holding its weights on one GPU."""
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
-                 dtype: torch.dtype = torch.float16):
+                 dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -93,6 +93,7 @@ class DinoViT:
         self.model_name = name
         self.embed_dim, self.depth, self.num_heads, self.patch_size = VIT_CONFIGS[name]
         self.device, self.dtype = torch.device(device), dtype
+        self.k_proj_fp32 = k_proj_fp32
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -122,6 +123,7 @@ class DinoViT:
                 n1w=f32(sd[p + "norm1.weight"]), n1b=f32(sd[p + "norm1.bias"]),
                 qkv_w=lp(sd[p + "attn.qkv.weight"]), qkv_b=lp(sd[p + "attn.qkv.bias"]),
                 k_w32=f32(sd[p + "attn.qkv.weight"][d:2 * d]), k_b32=f32(sd[p + "attn.qkv.bias"][d:2 * d]),
+                k_w=lp(sd[p + "attn.qkv.weight"][d:2 * d]),
                 proj_w=lp(sd[p + "attn.proj.weight"]), proj_b=lp(sd[p + "attn.proj.bias"]),
                 n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
                 fc1_w=lp(sd[p + "mlp.fc1.weight"]), fc1_b=lp(sd[p + "mlp.fc1.bias"]),
@@ -186,8 +188,13 @@ class DinoViT:
             f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
             pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
         blk = self.blocks[wb]
-        h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)
-        k = F.linear(h32, blk["k_w32"], blk["k_b32"])  # fp32 GEMM: the features handed to the eigen stage
+        if self.k_proj_fp32:  # all-fp32 K projection (3x slower GEMM; same operand rounding as nowhere else)
+            h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)
+            k = F.linear(h32, blk["k_w32"], blk["k_b32"])
+        else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
+            hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
+            k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
+            k += blk["k_b32"]
         return k[:, 1:, :].contiguous()
 
 
