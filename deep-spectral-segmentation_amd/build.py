@@ -21,6 +21,10 @@ LIB = LIBDIR / "libdss_hip.so"
 SOURCES = ["lib.hip", "preprocess.hip", "layernorm.hip", "attention.hip", "affinity.hip", "eigs.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# attention.hip: the softmax max-chains read MFMA results; in IEEE mode hipcc quiets every such value with an extra
+# v_max (64 of ~400 VALU instructions per key tile in a VALU-bound kernel).  No NaN can occur there (masking uses
+# -inf), so NaN-honouring and IEEE mode are switched off for this file only.
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def _hipcc() -> str:
@@ -35,7 +39,7 @@ def _digest() -> str:
     for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "dss_hip.h"]):
         h.update(f.name.encode())
         h.update(f.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -53,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = objdir / (Path(src).stem + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

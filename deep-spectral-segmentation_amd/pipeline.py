@@ -23,3 +23,41 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
     ev, vec, info = spectral.laplacian_eigs_from_features(k, K, normalize=normalize,
                                                           threshold_at_zero=threshold_at_zero, strict=strict)
     return k, ev, vec, info
+
+
+class OverlappedExtractor:
+    """Streams the two stages against each other: the ViT of sub-batch i+1 runs on the caller's stream while the
+    spectral stage (normalise -> affinity -> Lanczos) of sub-batch i runs on a side stream.  The eigensolver is
+    HBM-bound with one workgroup per image, the ViT's attention is MFMA/VALU-bound: they share the chip well.
+    Results are identical to ``features_and_eigs`` (same kernels, same order per image)."""
+
+    def __init__(self, model: DinoViT, K: int, vit_batch: int = 128, which_block: int = -1,
+                 normalize: bool = True, threshold_at_zero: bool = True):
+        self.model, self.K, self.vit_batch, self.which_block = model, K, vit_batch, which_block
+        self.normalize, self.threshold_at_zero = normalize, threshold_at_zero
+        self.side = torch.cuda.Stream(device=model.device)
+
+    @torch.no_grad()
+    def __call__(self, img_u8: torch.Tensor, keep_features: bool = False):
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)  # side-stream buffers from the previous call are free to be reused
+        outs, feats = [], []
+        for s in range(0, img_u8.shape[0], self.vit_batch):
+            k = self.model.extract_k(img_u8[s:s + self.vit_batch], which_block=self.which_block)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                k.record_stream(self.side)
+                outs.append(spectral.laplacian_eigs_from_features(
+                    k, self.K, normalize=self.normalize, threshold_at_zero=self.threshold_at_zero, strict=False))
+            if keep_features:
+                feats.append(k)
+        main.wait_stream(self.side)
+        ev = torch.cat([o[0] for o in outs])
+        vec = torch.cat([o[1] for o in outs])
+        info = torch.cat([o[2] for o in outs])
+        for o in outs:
+            for t in o:
+                t.record_stream(main)
+        return (torch.cat(feats) if keep_features else None), ev, vec, info

@@ -1,5 +1,5 @@
-import sys, torch, numpy as np
-sys.path.insert(0, '.')
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dss_amd
 from dss_amd import hip
 torch.manual_seed(0)
