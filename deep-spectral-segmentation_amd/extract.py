@@ -35,14 +35,30 @@ if __package__ in (None, ""):  # executed as a script: make the package importab
     import dss_amd  # noqa: F401
     from dss_amd import extract_utils as utils
     from dss_amd import spectral
-    from dss_amd.distributed import rank_world, local_device
+    from dss_amd.distributed import init_process_group, rank_world, local_device
 else:
     from . import extract_utils as utils
     from . import spectral
-    from .distributed import rank_world, local_device
+    from .distributed import init_process_group, rank_world, local_device
 
 _DTYPES = {"float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
            "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
+def _barrier():
+    """End-of-stage rendezvous of the ranks (the reference's ``accelerator.wait_for_everyone``, extract.py:114)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+
+
+def _make_output_dir_all_ranks(output_dir: str):
+    """Rank 0 runs the reference's (possibly interactive) non-empty check BEFORE any rank writes; the others wait."""
+    rank, _ = rank_world()
+    if rank == 0:
+        utils.make_output_dir(output_dir)
+    _barrier()
+    if rank != 0:
+        utils.make_output_dir(output_dir, check_if_empty=False)
 
 
 def _feature_dict(k: torch.Tensor, index: int, file: str, model_name: str, patch_size: int,
@@ -58,7 +74,7 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     """Extract features from a list of images (see module docstring).  ``batch_size`` is the maximum
     number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
     whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76)."""
-    utils.make_output_dir(output_dir)
+    _make_output_dir_all_ranks(output_dir)
     model_name = model_name.lower()
     if not ("dino" in model_name or "mocov3" in model_name):
         raise ValueError(model_name)
@@ -96,8 +112,7 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                 flush(batch)
             batch.append((idx, out, img, file))
         flush(batch)
-    if world > 1:
-        torch.distributed.barrier()
+    _barrier()
     print(f"Saved features to {output_dir}")
 
 
@@ -156,7 +171,7 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
                  multiprocessing: int = 0, batch_size: int = 64):
     """Extracts eigenvalues/eigenvectors from features (see module docstring).  ``multiprocessing`` is
     accepted for CLI compatibility and ignored; ``batch_size`` same-shape images share one kernel launch."""
-    utils.make_output_dir(output_dir)
+    _make_output_dir_all_ranks(output_dir)
     kwargs = dict(K=K, which_matrix=which_matrix, which_features=which_features,
                   which_color_matrix=which_color_matrix, normalize=normalize, threshold_at_zero=threshold_at_zero,
                   images_root=images_root, output_dir=output_dir, image_downsample_factor=image_downsample_factor,
@@ -190,12 +205,40 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
                 _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device)
     for key in list(pending):
         _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device)
-    if world > 1:
-        torch.distributed.barrier()
+    _barrier()
+
+
+def _extract_single_region_segmentations(inp: Tuple[int, Tuple[str, str]], threshold: float, output_dir: str):
+    """Immediate consumer of the eigen files (reference extract/extract.py:383-407): the
+    patch-level foreground mask ``eigenvectors[1] > threshold`` reshaped ``(H//P, W//P)``, saved as an 8-bit PNG
+    (0 / 255).  Pure host-side bookkeeping - no kernel involved."""
+    from PIL import Image
+
+    index, (feature_path, eigs_path) = inp
+    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
+    data_dict.update(torch.load(eigs_path, map_location="cpu", weights_only=False))
+    output_file = str(Path(output_dir) / f"{Path(data_dict['id'])}.png")
+    if Path(output_file).is_file():
+        print(f"Skipping existing file {str(output_file)}")
+        return
+    sizes = utils.get_image_sizes(data_dict)
+    h_patch, w_patch = sizes[5], sizes[6]
+    fiedler = data_dict["eigenvectors"][1].numpy()  # smallest non-trivial eigenvector
+    segmap = (fiedler > threshold).reshape(h_patch, w_patch)
+    Image.fromarray(segmap).convert("L").save(output_file)
+
+
+def extract_single_region_segmentations(features_dir: str, eigs_dir: str, output_dir: str, threshold: float = 0.0,
+                                        multiprocessing: int = 0):
+    """python extract.py extract_single_region_segmentations --features_dir F --eigs_dir E --output_dir O"""
+    utils.make_output_dir(output_dir)
+    fn = partial(_extract_single_region_segmentations, threshold=threshold, output_dir=output_dir)
+    utils.parallel_process(utils.get_paired_input_files(features_dir, eigs_dir), fn, multiprocessing)
 
 
 # ------------------------------------------------------------------------------------------ CLI
-COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs)
+COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs,
+                extract_single_region_segmentations=extract_single_region_segmentations)
 
 
 def _literal(s: str):
@@ -242,7 +285,10 @@ def parse_cli(argv: List[str]):
 def main(argv: Optional[List[str]] = None):
     torch.set_grad_enabled(False)  # extract/extract.py:838
     fn, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    init_process_group()  # no-op for a single process; under torchrun: one rank per GPU, round-robin shards
     fn(**kwargs)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -129,6 +129,21 @@ def get_image_sizes(data_dict: dict, downsample_factor: Optional[int] = None):
     return (b, c, h, w, p, h_patch, w_patch, h_patch * p, w_patch * p)
 
 
+def _get_files(p: str):
+    if Path(p).is_dir():
+        return sorted(Path(p).iterdir())
+    if Path(p).is_file():
+        return Path(p).read_text().splitlines()
+    raise ValueError(p)
+
+
+def get_paired_input_files(path1: str, path2: str):
+    """Pairs the i-th entry of two sorted directories / list files (reference extract_utils.py:82-95)."""
+    files1, files2 = _get_files(path1), _get_files(path2)
+    assert len(files1) == len(files2)
+    return list(enumerate(zip(files1, files2)))
+
+
 def make_output_dir(output_dir, check_if_empty: bool = True):
     output_dir = Path(output_dir)
     output_dir.mkdir(exist_ok=True, parents=True)

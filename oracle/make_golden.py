@@ -325,6 +325,26 @@ def check_vit_against_hf(model_name="dino_vits16", seed=3, atol=2e-4):
     return e1, e2
 
 
+def make_single_region_golden(ref):
+    """Reference extract_single_region_segmentations (extract.py:383-426) on a synthetic feature/eig pair."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as tmp:
+        fdir, edir, odir = Path(tmp) / "f", Path(tmp) / "e", Path(tmp) / "o"
+        fdir.mkdir(), edir.mkdir()
+        shape, patch = (1, 3, 75, 100), 16   # 4 x 6 patches
+        n = (shape[2] // patch) * (shape[3] // patch)
+        vec = rng.normal(size=(3, n)).astype(np.float32)
+        torch.save({"k": torch.zeros(1, n, 8), "indices": torch.tensor(0), "file": "seg_x.jpg", "id": "seg_x",
+                    "model_name": "dino_vits16", "patch_size": patch, "shape": shape}, fdir / "seg_x.pth")
+        torch.save({"eigenvalues": torch.zeros(3), "eigenvectors": torch.from_numpy(vec)}, edir / "seg_x.pth")
+        ref.extract_single_region_segmentations(features_dir=str(fdir), eigs_dir=str(edir), output_dir=str(odir))
+        png = np.array(Image.open(odir / "seg_x.png"))
+    np.savez_compressed(GOLDEN / "single_region.npz", eigenvectors=vec, shape=np.array(shape), patch=patch, png=png)
+    print(f"[golden] single_region: png {png.shape} {png.dtype} values {np.unique(png)}")
+
+
 def main():
     assert REFERENCE.is_dir(), "make_golden.py runs only where /root/reference is mounted"
     GOLDEN.mkdir(parents=True, exist_ok=True)
@@ -335,6 +355,7 @@ def main():
     make_index_probe(ref)
     make_feature_goldens(ref)
     make_eig_goldens(ref)
+    make_single_region_golden(ref)
 
 
 if __name__ == "__main__":

@@ -134,3 +134,42 @@ def test_cli_two_stage_roundtrip_and_resume(tmp_path, capsys):
     assert torch.load(tmp_path / "eigs2" / "b_000.pth", weights_only=True)["eigenvectors"].shape == (3, 48)
     with pytest.raises(NotImplementedError):
         extract._extract_eig((0, str(tmp_path / "feat" / "a_000.pth")), K=3, images_root="", output_dir=str(tmp_path / "eigs2"))
+
+
+def test_cli_two_ranks_shard_round_robin(tmp_path):
+    """N>1 on the real kernels: two processes (sharing this box's single GPU; gloo for the barriers) run the two
+    CLI stages; together they must produce exactly the single-process outputs, each file written once."""
+    import os
+    import subprocess
+    import sys
+
+    specs = [(f"im_{i:03d}.png", 30 + i, 96, 128) for i in range(7)]
+    _write_images(tmp_path / "images", specs)
+    (tmp_path / "images.txt").write_text("\n".join(s[0] for s in specs) + "\n")
+    repo = Path(__file__).resolve().parents[1]
+    cli = str(repo / "deep-spectral-segmentation_amd" / "extract.py")
+    env = dict(os.environ, DSS_DIST_BACKEND="gloo", DSS_ASSUME_YES="1")
+
+    def run(nproc, tag, port):
+        base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), cli]
+        subprocess.run(base + ["extract_features", "--images_list", str(tmp_path / "images.txt"), "--images_root",
+                               str(tmp_path / "images"), "--output_dir", str(tmp_path / f"feat{tag}"), "--model_name",
+                               "dino_vits16", "--batch_size", "4", "--synthetic_weights", "3"],
+                       check=True, env=env, timeout=600)
+        subprocess.run(base + ["extract_eigs", "--images_root", str(tmp_path / "images"), "--features_dir",
+                               str(tmp_path / f"feat{tag}"), "--output_dir", str(tmp_path / f"eigs{tag}"), "--K", "4"],
+                       check=True, env=env, timeout=600)
+
+    run(2, "2", 29533)
+    run(1, "1", 29534)
+    names = sorted(p.name for p in (tmp_path / "eigs1").iterdir())
+    assert names == sorted(p.name for p in (tmp_path / "eigs2").iterdir()) == [s[0][:-4] + ".pth" for s in specs]
+    for n in names:
+        f1 = torch.load(tmp_path / "feat1" / n, weights_only=True)
+        f2 = torch.load(tmp_path / "feat2" / n, weights_only=True)
+        assert int(f1["indices"]) == int(f2["indices"]) and torch.equal(f1["k"], f2["k"])
+        e1 = torch.load(tmp_path / "eigs1" / n, weights_only=True)
+        e2 = torch.load(tmp_path / "eigs2" / n, weights_only=True)
+        check_eigs(e2["eigenvectors"].numpy(), e2["eigenvalues"].numpy(), e1["eigenvectors"].numpy(),
+                   e1["eigenvalues"].numpy(), what=n)

@@ -121,3 +121,19 @@ def test_synthetic_inputs_are_portable():
     sd = synthetic.synthetic_state_dict("dino_vitb8", 0)
     assert sd["pos_embed"].shape == (1, 785, 768) and sd["blocks.11.attn.qkv.weight"].shape == (2304, 768)
     assert sd["patch_embed.proj.weight"].shape == (768, 3, 8, 8)
+
+
+def test_single_region_segmentation_matches_reference_golden(tmp_path, golden_dir):
+    """the eigen files' immediate consumer, against the reference's own output."""
+    from PIL import Image
+
+    g = np.load(golden_dir / "single_region.npz")
+    shape, patch, vec = tuple(int(v) for v in g["shape"]), int(g["patch"]), g["eigenvectors"]
+    (tmp_path / "f").mkdir(), (tmp_path / "e").mkdir()
+    n = vec.shape[1]
+    torch.save({"k": torch.zeros(1, n, 8), "indices": torch.tensor(0), "file": "seg_x.jpg", "id": "seg_x",
+                "model_name": "dino_vits16", "patch_size": patch, "shape": shape}, tmp_path / "f" / "seg_x.pth")
+    torch.save({"eigenvalues": torch.zeros(3), "eigenvectors": torch.from_numpy(vec)}, tmp_path / "e" / "seg_x.pth")
+    extract.extract_single_region_segmentations(str(tmp_path / "f"), str(tmp_path / "e"), str(tmp_path / "o"))
+    png = np.array(Image.open(tmp_path / "o" / "seg_x.png"))
+    assert png.dtype == g["png"].dtype and np.array_equal(png, g["png"])
