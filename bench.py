@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
-    ap.add_argument("--vit-batch", type=int, default=128, help="images per ViT forward")
+    ap.add_argument("--vit-batch", type=int, default=256, help="images per ViT forward")
     ap.add_argument("--model", default="dino_vits16")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--K", type=int, default=5)
