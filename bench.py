@@ -95,8 +95,12 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s")
         elif name == "affinity":
             m = metas[0]
-            flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle only: N(N+1)/2 dots of 2D flop
-            entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
+            if os.environ.get("DSS_AFFINITY", "split") == "fp32":   # exact fp32 MFMA build: MFMA-bound
+                flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle: N(N+1)/2 dots of 2D flop
+                entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
+            else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + 2N(N+1) out
+                byts = (4.0 * m["n"] * m["d"] + 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
+                entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")

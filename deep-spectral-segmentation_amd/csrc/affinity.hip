@@ -157,6 +157,150 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
   store_tile(acc11, 32, 32, act_r1 && act_c1);
 }
 
+// ================================================================================================
+// Split-f16 affinity: fp32-class accuracy at the f16 MFMA rate.
+//   x = hi + lo,  hi = f16(x),  lo = f16((x - hi) * 2^6) / 2^6          (|x| <= 1 after normalisation)
+//   <x_i, x_j> = hi_i.hi_j + (hi_i 2^-6).(lo_j 2^6) + (lo_i 2^6).(hi_j 2^-6) + O(2^-22)
+// Every f16 x f16 product is exact in the fp32 accumulator, the 2^+-6 scalings keep hi*2^-6 and lo*2^6 in the
+// normal f16 range (no subnormals), and all three products accumulate into ONE v_mfma_f32_32x32x16_f16
+// accumulator.  3 MFMAs of 32 cycles per 16 feature columns instead of 8 fp32 MFMAs of 64 cycles: the Gram
+// stops being MFMA-bound and sits on the HBM roofline (bytes: 4 B/elem of features in, 4 B/elem of packed W out).
+__global__ __launch_bounds__(256) void normalize_rows_split_kernel(const float* __restrict__ x, f16* __restrict__ hi,
+                                                                   f16* __restrict__ lo, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* xr = x + row * D;
+    float ss = 0.f;
+    for (int c = lane; c < (D >> 2); c += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const float denom = eps < 0.f ? 1.0f : fmaxf(sqrtf(wave_sum(ss)), eps);
+    for (int c = lane; c < (D >> 2); c += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      f16x4 h, l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float y = v[i] / denom;
+        h[i] = (f16)y;
+        l[i] = (f16)((y - (float)h[i]) * 64.0f);
+      }
+      *reinterpret_cast<f16x4*>(hi + row * D + 4 * c) = h;
+      *reinterpret_cast<f16x4*>(lo + row * D + 4 * c) = l;
+    }
+  }
+}
+
+static constexpr int SK = 32;        // feature columns per LDS stage (two k16 MFMA steps)
+static constexpr int SLD = SK + 8;   // 80-byte rows: 16 rows land on 16 distinct 16-byte bank slots
+
+__global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__ Hi, const f16* __restrict__ Lo,
+                                                         float* __restrict__ W, int N, int D, int ldw, int relu,
+                                                         size_t w_stride, int nimg) {
+  __shared__ __attribute__((aligned(16))) f16 Ah[GB][SLD];
+  __shared__ __attribute__((aligned(16))) f16 Al[GB][SLD];
+  __shared__ __attribute__((aligned(16))) f16 Bh[GB][SLD];
+  __shared__ __attribute__((aligned(16))) f16 Bl[GB][SLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nt = ldw / 64, nbk = (nt + 1) / 2, nblk = nbk * (nbk + 1) / 2;
+  int img, rem;
+  {  // XCD-aware order: all blocks of one image share an XCD (see gram_relu_kernel)
+    const int id = blockIdx.x, g8 = nimg & ~7;
+    if (id < nblk * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      img = (slot / nblk) * 8 + xcd;
+      rem = slot % nblk;
+    } else {
+      const int r = id - nblk * g8;
+      img = g8 + r / nblk;
+      rem = r % nblk;
+    }
+  }
+  int bi = 0;
+  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
+  const int bj = bi + rem;
+  const int I0 = bi * GB, J0 = bj * GB;
+  const f16* Hb = Hi + (long)img * N * D;
+  const f16* Lb = Lo + (long)img * N * D;
+  float* Wb = W + img * w_stride;
+
+  const int ti = 2 * bi + wr, tj = 2 * bj + wc;
+  const bool quad = ti < nt && tj < nt && tj >= ti;
+  const int ri0 = I0 + wr * 64, cj0 = J0 + wc * 64;
+  const bool act_r0 = quad && ri0 < N, act_r1 = quad && ri0 + 32 < N;
+  const bool act_c0 = quad && cj0 < N, act_c1 = quad && cj0 + 32 < N;
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  // staging: a [128 x 32] f16 panel is 512 16-byte chunks; thread -> chunks tid and tid + 256
+  const int srow = tid >> 2, scol = (tid & 3) * 8;
+  const f16 s_dn = (f16)0.015625f;  // 2^-6
+  for (int d0 = 0; d0 < D; d0 += SK) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = srow + 64 * p;
+      int ga = I0 + r; ga = ga < N ? ga : N - 1;
+      int gb = J0 + r; gb = gb < N ? gb : N - 1;
+      *reinterpret_cast<f16x8*>(&Ah[r][scol]) = *reinterpret_cast<const f16x8*>(Hb + (long)ga * D + d0 + scol);
+      *reinterpret_cast<f16x8*>(&Al[r][scol]) = *reinterpret_cast<const f16x8*>(Lb + (long)ga * D + d0 + scol);
+      *reinterpret_cast<f16x8*>(&Bh[r][scol]) = *reinterpret_cast<const f16x8*>(Hb + (long)gb * D + d0 + scol);
+      *reinterpret_cast<f16x8*>(&Bl[r][scol]) = *reinterpret_cast<const f16x8*>(Lb + (long)gb * D + d0 + scol);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < SK / 16; ++kk) {
+      const int c = 16 * kk + 8 * hh;
+      const f16x8 ah0 = *reinterpret_cast<const f16x8*>(&Ah[wr * 64 + li][c]);
+      const f16x8 ah1 = *reinterpret_cast<const f16x8*>(&Ah[wr * 64 + 32 + li][c]);
+      const f16x8 al0 = *reinterpret_cast<const f16x8*>(&Al[wr * 64 + li][c]);
+      const f16x8 al1 = *reinterpret_cast<const f16x8*>(&Al[wr * 64 + 32 + li][c]);
+      const f16x8 bh0 = *reinterpret_cast<const f16x8*>(&Bh[wc * 64 + li][c]);
+      const f16x8 bh1 = *reinterpret_cast<const f16x8*>(&Bh[wc * 64 + 32 + li][c]);
+      const f16x8 bl0 = *reinterpret_cast<const f16x8*>(&Bl[wc * 64 + li][c]);
+      const f16x8 bl1 = *reinterpret_cast<const f16x8*>(&Bl[wc * 64 + 32 + li][c]);
+      const f16x8 as0 = ah0 * s_dn, as1 = ah1 * s_dn, bs0 = bh0 * s_dn, bs1 = bh1 * s_dn;  // exact exponent shifts
+      if (act_r0 && act_c0) {
+        acc00 = mfma32x32x16(ah0, bh0, acc00); acc00 = mfma32x32x16(as0, bl0, acc00); acc00 = mfma32x32x16(al0, bs0, acc00);
+      }
+      if (act_r0 && act_c1) {
+        acc01 = mfma32x32x16(ah0, bh1, acc01); acc01 = mfma32x32x16(as0, bl1, acc01); acc01 = mfma32x32x16(al0, bs1, acc01);
+      }
+      if (act_r1 && act_c0) {
+        acc10 = mfma32x32x16(ah1, bh0, acc10); acc10 = mfma32x32x16(as1, bl0, acc10); acc10 = mfma32x32x16(al1, bs0, acc10);
+      }
+      if (act_r1 && act_c1) {
+        acc11 = mfma32x32x16(ah1, bh1, acc11); acc11 = mfma32x32x16(as1, bl1, acc11); acc11 = mfma32x32x16(al1, bs1, acc11);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!quad) return;
+  float* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
+    const int col = cj0 + csub + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = rsub + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int row = ri0 + lr;
+      float v = computed ? acc[r] : 0.f;
+      if (relu) v = fmaxf(v, 0.f);
+      if (row >= N || col >= N) v = 0.f;
+      tile[lr * 64 + csub + li] = v;
+    }
+  };
+  store_tile(acc00, 0, 0, act_r0 && act_c0);
+  store_tile(acc01, 0, 32, act_r0 && act_c1);
+  store_tile(acc10, 32, 0, act_r1 && act_c0);
+  store_tile(acc11, 32, 32, act_r1 && act_c1);
+}
+
 }  // namespace dss
 
 extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream) {
@@ -186,4 +330,36 @@ extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, i
                      D, ldw, threshold_at_zero ? 1 : 0, dss_affinity_elems(N), B);
   DSS_CHECK_LAUNCH("gram_relu");
   return DSS_OK;
+}
+
+extern "C" int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int normalize, float eps,
+                                  int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream) {
+  DSS_REQUIRE(feats && W && workspace, "dss_affinity_split: null pointer");
+  DSS_REQUIRE(B > 0 && N > 0 && D > 0, "dss_affinity_split: bad shape B=%d N=%d D=%d", B, N, D);
+  DSS_REQUIRE(D % dss::SK == 0, "dss_affinity_split: feature dim must be a multiple of %d (got %d)", dss::SK, D);
+  const size_t need = dss_affinity_split_workspace_bytes(B, N, D);
+  if (workspace_bytes < need)
+    return dss::fail(DSS_ERR_WORKSPACE, "dss_affinity_split: workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  dss::f16* hi = (dss::f16*)workspace;
+  dss::f16* lo = hi + (size_t)B * N * D;
+  const long rows = (long)B * N;
+  int blocks = (int)((rows + 3) / 4 > 65536 ? 65536 : (rows + 3) / 4);
+  // normalize == 0: eps is ignored and rows are split as they are (|x| <= ~1e4 keeps hi*2^-6 / lo*2^6 in f16 range)
+  hipLaunchKernelGGL(dss::normalize_rows_split_kernel, dim3(blocks), dim3(256), 0, s, feats, hi, lo, (int)rows, D,
+                     normalize ? eps : -1.0f);
+  DSS_CHECK_LAUNCH("normalize_rows_split");
+  const int ldw = dss_affinity_ld(N);
+  const int nbk = (ldw / 64 + 1) / 2;
+  const long nblocks = (long)(nbk * (nbk + 1) / 2) * B;
+  DSS_REQUIRE(nblocks < 2147483647L, "dss_affinity_split: too many blocks (%ld)", nblocks);
+  hipLaunchKernelGGL(dss::gram_split_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, hi, lo, W, N, D, ldw,
+                     threshold_at_zero ? 1 : 0, dss_affinity_elems(N), B);
+  DSS_CHECK_LAUNCH("gram_split");
+  return DSS_OK;
+}
+
+extern "C" size_t dss_affinity_split_workspace_bytes(int B, int N, int D) {
+  if (B <= 0 || N <= 0 || D <= 0) return 0;
+  return (size_t)2 * B * N * D * sizeof(dss::f16);
 }

@@ -35,6 +35,9 @@ SYMBOLS = {
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
     "dss_affinity": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_affinity_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dss_affinity_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
+                                   c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dss_laplacian_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_int, c_void_p, c_size_t, c_void_p]),
@@ -228,6 +231,22 @@ def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tenso
     with _timed("affinity", b=b, n=n, d=d):
         _check(load_library().dss_affinity(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(threshold_at_zero),
                                            _stream()), "dss_affinity")
+    return w
+
+
+def affinity_split(feats: torch.Tensor, normalize: bool = True, threshold_at_zero: bool = True,
+                   eps: float = 1e-12) -> torch.Tensor:
+    """RAW f32 ``[B, N, D]`` features -> packed ``W`` like ``affinity(normalize_rows(feats))`` but on the f16 MFMA
+    path with a two-term split of every feature (fp32-class accuracy, HBM-bound instead of fp32-MFMA-bound)."""
+    assert feats.dtype == torch.float32 and feats.dim() == 3
+    b, n, d = feats.shape
+    lib = load_library()
+    w = torch.empty((b, affinity_elems(n)), dtype=torch.float32, device=feats.device)
+    need = int(lib.dss_affinity_split_workspace_bytes(b, n, d))
+    ws = torch.empty(need, dtype=torch.uint8, device=feats.device)
+    with _timed("affinity", b=b, n=n, d=d):
+        _check(lib.dss_affinity_split(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(normalize), float(eps),
+                                      int(threshold_at_zero), _dev(ws, "ws"), need, _stream()), "dss_affinity_split")
     return w
 
 

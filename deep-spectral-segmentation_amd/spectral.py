@@ -7,6 +7,7 @@ device->host copy and no scipy.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -21,19 +22,26 @@ class EigsNotConverged(RuntimeError):
 @torch.no_grad()
 def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
                                  threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
-                                 max_restarts: int = 0, max_bytes: int = 24 << 30,
-                                 strict: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                                 max_restarts: int = 0, max_bytes: int = 24 << 30, strict: bool = True,
+                                 affinity_mode: Optional[str] = None
+                                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
     ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
 
     * eigenvalues ascending (``lambda_0 ~ 0``), eigenvectors D-orthonormal, sign rule applied - the
       conventions of the reference's ``.pth`` schema.
     * images are processed in chunks whose affinity matrices fit in ``max_bytes`` of HBM.
+    * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
+      (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.
     * ``strict``: raise ``EigsNotConverged`` if any image exhausted its restart budget (the reference
       would have raised ``ArpackNoConvergence`` into a bare ``except``)."""
     if feats.dim() == 2:
         feats = feats[None]
     assert feats.dim() == 3 and feats.dtype == torch.float32
+    if affinity_mode is None:
+        affinity_mode = os.environ.get("DSS_AFFINITY", "split")
+    if affinity_mode not in ("split", "fp32"):
+        raise ValueError(f"affinity_mode must be 'split' or 'fp32' (got {affinity_mode!r})")
     b, n, d = feats.shape
     if not K < n:
         raise ValueError(f"need K < N (K={K}, N={n})")
@@ -43,9 +51,12 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     evals, evecs, infos = [], [], []
     for s in range(0, b, chunk):
         f = feats[s:s + chunk].contiguous()
-        if normalize:
-            f = hip.normalize_rows(f)
-        w = hip.affinity(f, threshold_at_zero)
+        if affinity_mode == "fp32" or d % 32 != 0:  # exact fp32 MFMA (bitwise an fmaf chain), MFMA-bound
+            if normalize:
+                f = hip.normalize_rows(f)
+            w = hip.affinity(f, threshold_at_zero)
+        else:  # split-f16 (fp32-class accuracy, ~1e-7), HBM-bound; fused with the row normalisation
+            w = hip.affinity_split(f, normalize, threshold_at_zero)
         ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts)
         evals.append(ev), evecs.append(vec), infos.append(info)
         del w

@@ -92,6 +92,15 @@ size_t dss_affinity_elems(int N);
 int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
                  void* stream);
 
+/* Same W (same packed layout), fused with the row normalisation, at the f16 MFMA rate with fp32-class accuracy:
+ * each normalised feature is split x = hi + lo (two f16 values) and <x_i,x_j> = hi.hi + hi.lo + lo.hi is
+ * accumulated in fp32 (error ~1e-7; the fp32 kernel above is bitwise an fmaf chain).  This moves the affinity
+ * build from the fp32-MFMA roofline to the HBM roofline.  feats: RAW features [B, N, D] f32; normalize != 0
+ * applies extract.py:148 (eps as in dss_normalize_rows).  workspace: dss_affinity_split_workspace_bytes(B, N, D). */
+size_t dss_affinity_split_workspace_bytes(int B, int N, int D);
+int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int normalize, float eps,
+                       int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a13-a15: degree, normalised Laplacian, K smallest generalized eigenpairs, sign rule -------
  * extract/extract_utils.py:207-220  d = W 1 ; d[d < 1e-12] = 1
  * extract/extract.py:227            eigsh(D - W, k=K, sigma=0, which='LM', M=D)

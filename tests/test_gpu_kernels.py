@@ -147,6 +147,18 @@ def test_affinity_matches_fp64(b, n, d):
     assert torch.equal(w, w.transpose(1, 2))         # diagonal tiles are stored in full and bit-symmetric
     wneg = hip.affinity_to_dense(hip.affinity(fn, threshold_at_zero=False), n).cpu()
     assert (wneg[:, :n, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
+    # split-f16 path (default of the spectral stage): same packed layout, fp32-class accuracy, fused normalisation
+    ws = hip.affinity_to_dense(hip.affinity_split(feats.to(DEV)), n).cpu()
+    assert torch.equal(ws[:, :, n:], torch.zeros(b, ld, ld - n)) and torch.equal(ws[:, n:, :], torch.zeros(b, ld - n, ld))
+    assert (ws[:, :n, :n].double() - ref).abs().max().item() < 2e-6
+    # symmetric to rounding only: inside a diagonal tile the two cross terms accumulate in the opposite order
+    assert (ws - ws.transpose(1, 2)).abs().max().item() < 2e-7
+    wsn = hip.affinity_to_dense(hip.affinity_split(feats.to(DEV), threshold_at_zero=False), n).cpu()
+    assert (wsn[:, :n, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
+    raw = feats.to(DEV) * 0.37   # un-normalised features (normalize=False path)
+    wr = hip.affinity_to_dense(hip.affinity_split(raw, normalize=False), n).cpu()
+    rr = (raw.double().cpu() @ raw.double().cpu().transpose(1, 2)).clamp_min(0)
+    assert (wr[:, :n, :n].double() - rr).abs().max().item() < 2e-6 * max(1.0, rr.max().item())
 
 
 # ----------------------------------------------------------------------------- eigen stage
@@ -167,11 +179,12 @@ def test_eigs_match_reference_goldens(path):
         assert not (0.5 < (vec[0, k] > 0).float().mean().item() < 1.0)  # sign-rule post-condition
 
 
-def test_eigs_batch_against_oracle():
-    """A batch of different images in ONE launch vs the scipy oracle image by image."""
+@pytest.mark.parametrize("mode", ["split", "fp32"])
+def test_eigs_batch_against_oracle(mode):
+    """A batch of different images in ONE launch vs the scipy oracle image by image (both affinity builds)."""
     n, d, K, b = 400, 384, 5, 9
     feats = np.stack([synthetic.synthetic_features("blobs", n, d, 900 + i, (20, 20)) for i in range(b)])
-    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), K)
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), K, affinity_mode=mode)
     assert (info > 0).all()
     for i in range(b):
         lam, v = spectral_ref.ref_laplacian_eigs(torch.from_numpy(feats[i])[None], K)
