@@ -105,13 +105,24 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                        str(out))
         batch.clear()
 
-    batch: List[Tuple[int, Path, torch.Tensor, str]] = []
+    # Real datasets (VOC) mix image sizes: bucket by shape so every ViT launch is a full same-shape batch.  At most
+    # `max_pending` decoded images wait in the buckets; beyond that the fullest bucket is flushed early.
+    buckets: Dict[Tuple[int, ...], List[Tuple[int, Path, torch.Tensor, str]]] = {}
+    bs, max_pending, n_pending = max(1, int(batch_size)), 8 * max(1, int(batch_size)), 0
     with ThreadPoolExecutor(max_workers=8) as pool:  # the reference's 8 loader workers (extract.py:60)
         for (idx, out), (img, file, _) in zip(todo, pool.map(lambda t: dataset[t[0]], todo)):
-            if batch and (tuple(batch[0][2].shape) != tuple(img.shape) or len(batch) >= max(1, int(batch_size))):
-                flush(batch)
-            batch.append((idx, out, img, file))
-        flush(batch)
+            bucket = buckets.setdefault(tuple(img.shape), [])
+            bucket.append((idx, out, img, file))
+            n_pending += 1
+            if len(bucket) >= bs:
+                n_pending -= len(bucket)
+                flush(bucket)
+            elif n_pending >= max_pending:
+                fullest = max(buckets.values(), key=len)
+                n_pending -= len(fullest)
+                flush(fullest)
+        for bucket in buckets.values():
+            flush(bucket)
     _barrier()
     print(f"Saved features to {output_dir}")
 

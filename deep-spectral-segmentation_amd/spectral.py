@@ -23,7 +23,7 @@ class EigsNotConverged(RuntimeError):
 def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
                                  threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
                                  max_restarts: int = 0, max_bytes: int = 24 << 30, strict: bool = True,
-                                 affinity_mode: Optional[str] = None
+                                 affinity_mode: Optional[str] = None, retry: bool = True
                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
     ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
@@ -33,8 +33,9 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     * images are processed in chunks whose affinity matrices fit in ``max_bytes`` of HBM.
     * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
       (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.
-    * ``strict``: raise ``EigsNotConverged`` if any image exhausted its restart budget (the reference
-      would have raised ``ArpackNoConvergence`` into a bare ``except``)."""
+    * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
+    * ``strict``: raise ``EigsNotConverged`` if an image is still unconverged after that (the reference would
+      have raised ``ArpackNoConvergence`` into a bare ``except``)."""
     if feats.dim() == 2:
         feats = feats[None]
     assert feats.dim() == 3 and feats.dtype == torch.float32
@@ -61,6 +62,16 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         evals.append(ev), evecs.append(vec), infos.append(info)
         del w
     ev, vec, info = torch.cat(evals), torch.cat(evecs), torch.cat(infos)
+    if retry and bool((info <= 0).any()):
+        # The reference reacts to an ARPACK failure by re-solving in 'SM' mode (extract.py:228-229).  Here the
+        # images that exhausted their restart budget are re-solved alone with the largest Krylov space and a
+        # 10x restart budget; everything else keeps its first answer.
+        bad = (info <= 0).nonzero().flatten()
+        ev2, vec2, info2 = laplacian_eigs_from_features(
+            feats[bad], K, normalize=normalize, threshold_at_zero=threshold_at_zero, ncv=64,
+            tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60), max_bytes=max_bytes,
+            strict=False, affinity_mode=affinity_mode, retry=False)
+        ev[bad], vec[bad], info[bad] = ev2, vec2, info2
     if strict:
         bad = (info <= 0).nonzero().flatten().tolist()
         if bad:

@@ -63,6 +63,38 @@ def test_end_to_end_eigenvectors_within_1e4_of_cpu_path(dtype):
                    lam_tol=lam_tol)
 
 
+@pytest.mark.timeout(900)
+def test_config5_mixed_size_vitb8_k20():
+    """BASELINE config 5 shape: dino_vitb8, an odd-sized 320-640 px image (not a multiple of 8), K=20, f16
+    features + f32 eigensolve, whole GPU path vs whole CPU oracle path."""
+    model, ref = _models("dino_vitb8", 4, 0.0, torch.float16)
+    h, w, K = 427, 333, 20          # -> 53 x 41 = 2173 patches after the crop
+    img = synthetic.synthetic_image(9, h, w)
+    k, ev, vec, info = pipeline.features_and_eigs(model, torch.from_numpy(img)[None].to(DEV), K)
+    assert info.item() > 0 and tuple(vec.shape) == (1, K, (h // 8) * (w // 8))
+    kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
+    assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
+    lam, v = spectral_ref.ref_laplacian_eigs(kr, K)
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what="config5", lam_tol=1e-3)
+
+
+def test_cli_buckets_mixed_shapes(tmp_path):
+    """Interleaved image sizes: the CLI buckets by shape; every image still gets its own correct B=1 file."""
+    specs = [(f"m_{i:02d}.png", 50 + i, (96, 128) if i % 2 else (128, 96)) for i in range(6)]
+    _write_images(tmp_path / "images", [(n, idx, hw[0], hw[1]) for n, idx, hw in specs])
+    (tmp_path / "images.txt").write_text("\n".join(s[0] for s in specs) + "\n")
+    extract.main(["extract_features", "--images_list", str(tmp_path / "images.txt"), "--images_root",
+                  str(tmp_path / "images"), "--output_dir", str(tmp_path / "feat"), "--model_name", "dino_vits16",
+                  "--batch_size", "2", "--synthetic_weights", "3"])
+    sd = synthetic.synthetic_state_dict("dino_vits16", 3)
+    ref = vit_ref.build_ref_vit("dino_vits16", sd)
+    for i, (n, idx, hw) in enumerate(specs):
+        d = torch.load(tmp_path / "feat" / (n[:-4] + ".pth"), weights_only=True)
+        assert int(d["indices"]) == i and d["shape"] == (1, 3, hw[0], hw[1]) and d["file"] == n
+        kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(synthetic.synthetic_image(idx, hw[0], hw[1])))
+        assert ((d["k"] - kr).norm() / kr.norm()).item() < 4e-3
+
+
 def _write_images(root: Path, specs):
     from PIL import Image
 
