@@ -50,7 +50,8 @@ class OverlappedExtractor:
                 self.side.wait_event(ready)
                 k.record_stream(self.side)
                 outs.append(spectral.laplacian_eigs_from_features(
-                    k, self.K, normalize=self.normalize, threshold_at_zero=self.threshold_at_zero, strict=False))
+                    k, self.K, normalize=self.normalize, threshold_at_zero=self.threshold_at_zero, strict=False,
+                    retry=False))
             if keep_features:
                 feats.append(k)
         main.wait_stream(self.side)

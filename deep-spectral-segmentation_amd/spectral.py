@@ -34,6 +34,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
       (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
+      Checking for them reads ``info`` back (one device->host sync per call): throughput loops that must keep
+      the host running ahead pass ``retry=False, strict=False`` and inspect ``info`` once at the end.
     * ``strict``: raise ``EigsNotConverged`` if an image is still unconverged after that (the reference would
       have raised ``ArpackNoConvergence`` into a bare ``except``)."""
     if feats.dim() == 2:
