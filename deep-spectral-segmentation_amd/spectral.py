@@ -69,6 +69,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         # images that exhausted their restart budget are re-solved alone with the largest Krylov space and a
         # 10x restart budget; everything else keeps its first answer.
         bad = (info <= 0).nonzero().flatten()
+        print(f"[dss] {bad.numel()} of {info.numel()} images exhausted the Lanczos restart budget "
+              f"(passes {(-info[bad]).tolist()[:4]}...): re-solving them with ncv=64")
         ev2, vec2, info2 = laplacian_eigs_from_features(
             feats[bad], K, normalize=normalize, threshold_at_zero=threshold_at_zero, ncv=64,
             tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60), max_bytes=max_bytes,
