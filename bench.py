@@ -130,7 +130,7 @@ def pmc_traffic(kernel, a):
         c = d.get("config", {})
         if (c.get("model"), c.get("size"), c.get("K"), c.get("batch"), c.get("vit_batch")) == \
                 (a.model, a.size, a.K, a.batch, a.vit_batch) and kernel in d.get("kernels", {}):
-            best = {"bytes_per_launch": d["kernels"][kernel]["hbm_bytes_per_launch"], "source": f"profiles/{f.name}"}
+            best = (d["kernels"][kernel]["hbm_bytes_per_launch"], f"profiles/{f.name}")
     return best
 
 
@@ -241,8 +241,10 @@ def main():
         kern = summarize_timers(timers, n_patches, dim, depth)
         dominant = max((k for k in kern if "achieved" in kern[k]), key=lambda k: kern[k]["total_ms"])
         d = kern[dominant]
+        traffic = pmc_traffic(dominant, a)  # HBM bytes per launch from the committed rocprofv3 PMC passes, or None
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": pmc_traffic(dominant, a)}
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic[0] if traffic else None,
+                    "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE)*1024", "traffic_source": traffic[1] if traffic else None}
         out = {
             "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
             "value": round(a.steps * a.batch * world / elapsed, 2), "unit": "images/s",
