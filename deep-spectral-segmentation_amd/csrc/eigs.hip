@@ -53,7 +53,16 @@ extern "C" size_t dss_eigs_workspace_bytes(int B, int N, int K, int ncv) {
 extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
                                   int32_t* info, int ncv, float tol, int max_restarts, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  return dss_symmetric_eigs(W, B, N, K, DSS_EIGS_NORMALIZED_LAPLACIAN, eigenvalues, eigenvectors, info, ncv, tol,
+                            max_restarts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode, float* eigenvalues,
+                                  float* eigenvectors, int32_t* info, int ncv, float tol, int max_restarts,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
   DSS_REQUIRE(W && eigenvalues && eigenvectors && info && workspace, "dss_laplacian_eigs: null pointer");
+  DSS_REQUIRE(mode == DSS_EIGS_NORMALIZED_LAPLACIAN || mode == DSS_EIGS_AFFINITY_LM || mode == DSS_EIGS_LAPLACIAN,
+              "dss_symmetric_eigs: unknown mode %d", mode);
   DSS_REQUIRE(B > 0 && N > 1 && K > 0, "dss_laplacian_eigs: bad shape B=%d N=%d K=%d", B, N, K);
   DSS_REQUIRE(K < N, "dss_laplacian_eigs: need K < N (K=%d, N=%d)", K, N);
   ncv = dss::resolve_ncv(N, K, ncv);
@@ -69,6 +78,7 @@ extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* ei
   P.keep = (ncv + K) / 2;  // tuned on tests/golden with the host emulation (tests/host_emul)
   P.max_restarts = max_restarts > 0 ? max_restarts : 60;
   P.tol = tol > 0.f ? tol : 2e-6f;
+  P.mode = mode;
   const dss::EigsLds L = dss::eigs_lds_layout(ld, ncv);
   DSS_REQUIRE(L.total <= 160 * 1024, "dss_laplacian_eigs: N=%d needs %zu B of LDS (> 160 KiB)", N, L.total);
   hipError_t e = hipFuncSetAttribute((const void*)dss::laplacian_eigs_kernel,

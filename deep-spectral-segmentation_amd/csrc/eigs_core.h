@@ -56,6 +56,15 @@ namespace dss {
 
 static constexpr int EIGS_MAX_NCV = 64;
 
+// Operator / selection modes (one Lanczos, three problems of the reference's _extract_eig):
+//   EIGS_NORMALIZED_LAPLACIAN  S = D^-1/2 W D^-1/2, K largest theta; lambda = 1 - theta, v = D^-1/2 u
+//                              (extract.py:227  eigsh(D - W, k, sigma=0, which='LM', M=D))
+//   EIGS_AFFINITY_LM           operator W, K eigenpairs of largest MAGNITUDE; value = theta, v = u
+//                              (extract.py:171  eigsh(W, which='LM', k); also :161-163 svd(feats) via W = F F^T)
+//   EIGS_LAPLACIAN             operator W - D = -(D - W), K largest theta; lambda = -theta, v = u
+//                              (extract.py:232  eigsh(D - W, k, sigma=0, which='LM'), lapnorm=False)
+enum { EIGS_NORMALIZED_LAPLACIAN = 0, EIGS_AFFINITY_LM = 1, EIGS_LAPLACIAN = 2 };
+
 struct EigsParams {
   int N;            // matrix order (patches)
   int ld;           // row stride of W in floats (multiple of 64, pad columns are zero)
@@ -64,6 +73,7 @@ struct EigsParams {
   int keep;         // Ritz vectors kept at a restart (K <= keep <= m - 2)
   int max_restarts;
   float tol;
+  int mode;         // EIGS_* above
 };
 
 // LDS carve (bytes) for one image; all offsets are multiples of 16.
@@ -278,7 +288,7 @@ DSS_DEV void basis_axpy(const float* V, int ldv, int nvec, float* ws, int N, con
 //   3. one thread per (pair, column): rows p,q of A                            (A <- J^T A)
 // with a barrier after each step.  A and Vr are column-major with leading dimension m (A is symmetric).
 // On exit theta[c] = A[c][c], Vr[:, c] = eigenvector, perm = ranks (descending theta).
-DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm) {
+DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm, bool by_magnitude) {
   const int M = (m + 1) & ~1, np = M / 2;
   for (int sweep = 0; sweep < 30; ++sweep) {
     if (DSS_TID == 0) sm->flag = 0;
@@ -336,9 +346,9 @@ DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm) {
   DSS_SYNC();
   for (int c = DSS_TID; c < m; c += DSS_NT) {
     int rank = 0;
-    const double tc = sm->theta[c];
+    const double tc = by_magnitude ? fabs(sm->theta[c]) : sm->theta[c];
     for (int j = 0; j < m; ++j) {
-      const double tj = sm->theta[j];
+      const double tj = by_magnitude ? fabs(sm->theta[j]) : sm->theta[j];
       rank += (tj > tc || (tj == tc && j < c)) ? 1 : 0;
     }
     sm->perm[rank] = c;
@@ -349,7 +359,8 @@ DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm) {
 // Rayleigh-Ritz on the projected matrix T (m x m): diagonal alpha, arrow column l (after a restart),
 // off-diagonal beta[j] = T[j][j+1] for j >= l.  Returns the number of the K wanted Ritz pairs whose residual
 // |beta_last * z_{m-1,i}| exceeds tol * max(|theta_i|, 1e-3).  Leaves Vr / sm->theta / sm->perm set.
-DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double beta_last, float tol, EigsSmall* sm) {
+DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double beta_last, float tol, EigsSmall* sm,
+                          bool by_magnitude) {
   for (int idx = DSS_TID; idx < m * m; idx += DSS_NT) {
     const int c = idx / m, r = idx - c * m;
     double t = 0.;
@@ -363,14 +374,16 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
     Vr[idx] = r == c ? 1.0 : 0.0;
   }
   DSS_SYNC();
-  jacobi_eig(A, Vr, m, sm);
+  jacobi_eig(A, Vr, m, sm, by_magnitude);
+  double tmax = 0.;  // tolerance floor relative to the largest Ritz value in magnitude (1 for the normalised Laplacian)
+  for (int c = 0; c < m; ++c) tmax = fabs(sm->theta[c]) > tmax ? fabs(sm->theta[c]) : tmax;
   int nbad = 0;
   for (int i = 0; i < K; ++i) {
     if (i >= m) { ++nbad; continue; }
     const int c = sm->perm[i];
     const double res = fabs(beta_last * Vr[(size_t)c * m + (m - 1)]);
     const double th = fabs(sm->theta[c]);
-    if (res > (double)tol * (th > 1e-3 ? th : 1e-3)) ++nbad;
+    if (res > (double)tol * (th > 1e-3 * tmax ? th : 1e-3 * tmax)) ++nbad;
   }
   return nbad;
 }
@@ -395,15 +408,19 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
   float* dis = gws + (size_t)2 * (mmax + 1) * ldv;
   int passes = 0;
 
-  // ---- degree: d = W 1 ; clamp ; dis = d^-1/2 -------------------------------------------------
-  for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? 1.0f : 0.0f;
-  DSS_SYNC();
-  matvec_sym(W, N, ld, xs, ws, nullptr, false);
-  ++passes;
-  for (int e = DSS_TID; e < ld; e += DSS_NT) {
-    float d = e < N ? ws[e] : 1.0f;
-    if (d < 1e-12f) d = 1.0f;
-    dis[e] = e < N ? 1.0f / sqrtf(d) : 0.0f;
+  // ---- degree: d = W 1 ; clamp (extract_utils.py:218) ; dis = d^-1/2 (normalised) or d itself (plain Laplacian) ----
+  const int mode = P.mode;
+  const bool by_mag = mode == EIGS_AFFINITY_LM;
+  if (mode != EIGS_AFFINITY_LM) {
+    for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? 1.0f : 0.0f;
+    DSS_SYNC();
+    matvec_sym(W, N, ld, xs, ws, nullptr, false);
+    ++passes;
+    for (int e = DSS_TID; e < ld; e += DSS_NT) {
+      float d = e < N ? ws[e] : 1.0f;
+      if (d < 1e-12f) d = 1.0f;
+      dis[e] = e >= N ? 0.0f : (mode == EIGS_NORMALIZED_LAPLACIAN ? 1.0f / sqrtf(d) : d);
+    }
   }
   // ---- start vector -------------------------------------------------------------------------------
   float nrm2 = 0.f;
@@ -425,9 +442,19 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
     bool breakdown = false, early = false;
     for (int j = l; j < mmax; ++j) {
       const float* vj = Va + (size_t)j * ldv;
-      for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? dis[e] * vj[e] : 0.0f;
-      DSS_SYNC();
-      matvec_sym(W, N, ld, xs, ws, dis, true);
+      if (mode == EIGS_NORMALIZED_LAPLACIAN) {
+        for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? dis[e] * vj[e] : 0.0f;
+        DSS_SYNC();
+        matvec_sym(W, N, ld, xs, ws, dis, true);              // w = D^-1/2 W D^-1/2 v
+      } else {
+        for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? vj[e] : 0.0f;
+        DSS_SYNC();
+        matvec_sym(W, N, ld, xs, ws, nullptr, false);         // w = W v
+        if (mode == EIGS_LAPLACIAN) {                         // w = W v - D v = -(D - W) v
+          for (int e = DSS_TID; e < N; e += DSS_NT) ws[e] -= dis[e] * vj[e];
+          DSS_SYNC();
+        }
+      }
       ++passes;
       // classical Gram-Schmidt, two passes (full reorthogonalisation against V[0..j])
       basis_dots(Va, ldv, j + 1, ws, N, sm->coef);
@@ -462,13 +489,13 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
       DSS_SYNC();
       // mid-cycle convergence check every 2 steps: a converged image stops streaming W at once
       if (m < mmax && m >= K + 3 && m > l + 1 && ((m - l) & 1) == 0) {
-        if (rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm) == 0) { early = true; break; }
+        if (rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm, by_mag) == 0) { early = true; break; }
         DSS_SYNC();
       }
     }
     // ---- Rayleigh-Ritz on the full basis (skipped when a mid-cycle check already converged) -----------------
     int nbad = 0;
-    if (!early) nbad = rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm);
+    if (!early) nbad = rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm, by_mag);
     converged = (nbad == 0);
     if (converged || breakdown || restart >= P.max_restarts) break;
     // ---- thick restart: keep the best `keep` Ritz vectors -----------------------------------------------
@@ -522,7 +549,7 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
     for (int e = DSS_TID; e < N; e += DSS_NT) {
       float u = 0.f;
       for (int j = 0; j < m; ++j) u += Va[(size_t)j * ldv + e] * Zf[(size_t)i * m + j];
-      const float v = u * dis[e];
+      const float v = mode == EIGS_NORMALIZED_LAPLACIAN ? u * dis[e] : u;
       ws[e] = v;
       pos += v > 0.f ? 1 : 0;
     }
@@ -532,7 +559,10 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
     for (int e = DSS_TID; e < N; e += DSS_NT) eigenvectors[(size_t)i * N + e] = sgn * ws[e];
     DSS_SYNC();
   }
-  for (int i = DSS_TID; i < K; i += DSS_NT) eigenvalues[i] = (float)(1.0 - sm->theta[sm->perm[i]]);
+  for (int i = DSS_TID; i < K; i += DSS_NT) {
+    const double th = sm->theta[sm->perm[i]];
+    eigenvalues[i] = (float)(mode == EIGS_NORMALIZED_LAPLACIAN ? 1.0 - th : (mode == EIGS_LAPLACIAN ? -th : th));
+  }
   if (DSS_TID == 0) *info = converged ? passes : -passes;
 }
 

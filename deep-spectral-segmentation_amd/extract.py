@@ -13,9 +13,11 @@ scripts (object-localization/main.py:254-272, extract.py:283-426) consume the ou
 Under ``python -m torch.distributed.run --nproc-per-node N`` every rank takes the items
 ``i % world_size == rank`` of the sorted work list (one process per GPU, no collective on the data path).
 
-Scope: ``which_matrix`` in {'laplacian', 'matting_laplacian'} with ``image_color_lambda == 0`` and
-``lapnorm=True`` - the ``extract_eigs`` defaults and the README recipes.  Other branches of the reference
-(``affinity*``, colour affinities, feature upsampling, ``lapnorm=False``) raise ``NotImplementedError``.
+Scope: ``which_matrix`` in {'laplacian', 'matting_laplacian'} (``lapnorm`` True or False), 'affinity' and
+'affinity_svd', all with ``image_color_lambda == 0`` - the ``extract_eigs`` defaults, the README recipes and the
+reference's other solver branches, including feature upsampling (``image_downsample_factor``).  Colour affinities
+(``image_color_lambda > 0``, pymatting KNN / random-walk) and the dead ``affinity_torch`` branch raise
+``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -172,15 +174,17 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     print(f"Saved features to {output_dir}")
 
 
-def _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, patch_size):
+def _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, patch_size) -> str:
+    """Validates the option combination and returns the ``spectral`` problem name it maps to."""
+    if which_matrix == "affinity_torch":
+        raise NotImplementedError("which_matrix='affinity_torch' is dead code in the reference (torch.eig was removed)")
+    if which_matrix in ("affinity", "affinity_svd"):
+        return which_matrix  # these branches ignore the Laplacian / colour options (extract.py:159-172)
     if which_matrix not in ("laplacian", "matting_laplacian"):
-        raise NotImplementedError(f"which_matrix={which_matrix!r}: only the (matting_)laplacian path is built")
-    if not lapnorm:
-        raise NotImplementedError("lapnorm=False (un-normalised Laplacian) is not built")
+        raise ValueError(f"unknown which_matrix {which_matrix!r}")
     if image_color_lambda > 0:
         raise NotImplementedError("image_color_lambda > 0 (KNN / random-walk colour affinities) is not built")
-    if image_downsample_factor is not None and image_downsample_factor != patch_size:
-        raise NotImplementedError("feature upsampling (image_downsample_factor != patch size) is not built")
+    return "laplacian" if lapnorm else "laplacian_unnormalized"
 
 
 def _load_features(features_file: str, which_features: str) -> Tuple[dict, torch.Tensor]:
@@ -191,15 +195,29 @@ def _load_features(features_file: str, which_features: str) -> Tuple[dict, torch
     return data_dict, feats.to(torch.float32)
 
 
+def _upsample_spec(data_dict: dict, which_matrix: str, image_downsample_factor: Optional[int]):
+    """extract.py:178-188: the Laplacian branches resize the features to the (H_pad//f, W_pad//f) grid when that
+    differs from the patch grid; the affinity branches never do."""
+    if which_matrix not in ("laplacian", "matting_laplacian") or image_downsample_factor is None:
+        return None
+    _, _, _, _, p, h_patch, w_patch, h_pad, w_pad = utils.get_image_sizes(data_dict)
+    lr = (h_pad // image_downsample_factor, w_pad // image_downsample_factor)
+    return None if lr == (h_patch, w_patch) else ((h_patch, w_patch), lr)
+
+
 def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: bool, threshold_at_zero: bool,
-                   device: torch.device, saver: Optional["_AsyncSaver"] = None):
+                   device: torch.device, saver: Optional["_AsyncSaver"] = None, problem: str = "laplacian",
+                   upsample=None):
     feats = torch.stack([f for _, f in items]).to(device, non_blocking=True)
     ev, vec, _ = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
-                                                       threshold_at_zero=threshold_at_zero)
+                                                       threshold_at_zero=threshold_at_zero, problem=problem,
+                                                       upsample=upsample)
     ev, vec = ev.cpu(), vec.cpu()
     for j, (output_file, _) in enumerate(items):
-        # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32
-        obj = {"eigenvalues": ev[j].clone(), "eigenvectors": vec[j].clone()}
+        # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32; the 'affinity'
+        # branch stores its eigenvalues as a raw numpy array (:171,243) - kept, consumers load it that way
+        vals = ev[j].clone()
+        obj = {"eigenvalues": vals.numpy() if problem == "affinity" else vals, "eigenvectors": vec[j].clone()}
         if saver is None:
             torch.save(obj, output_file)
         else:
@@ -219,9 +237,11 @@ def _extract_eig(inp: Tuple[int, str], K: int, images_root: str, output_dir: str
     if Path(output_file).is_file():
         print(f"Skipping existing file {str(output_file)}")
         return
-    _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, data_dict["patch_size"])
+    problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
+                                 data_dict["patch_size"])
     utils.get_image_sizes(data_dict)  # keeps the reference's B == 1 assertion
-    _run_eig_batch([(output_file, feats)], K, normalize, threshold_at_zero, local_device())
+    _run_eig_batch([(output_file, feats)], K, normalize, threshold_at_zero, local_device(), problem=problem,
+                   upsample=_upsample_spec(data_dict, which_matrix, image_downsample_factor))
 
 
 def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_matrix: str = "laplacian",
@@ -248,7 +268,7 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         data_dict, feats = _load_features(str(f), which_features)
         return data_dict, feats
 
-    pending: Dict[Tuple[int, int], List[Tuple[str, torch.Tensor]]] = {}
+    pending: Dict[Tuple, List[Tuple[str, torch.Tensor]]] = {}
     saver = _AsyncSaver()
     with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
         for data_dict, feats in _bounded_map(pool, load, mine, 4 * max(1, int(batch_size))):
@@ -257,15 +277,16 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             if Path(output_file).is_file():
                 print(f"Skipping existing file {str(output_file)}")
                 continue
-            _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
-                               data_dict["patch_size"])
+            problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
+                                         data_dict["patch_size"])
             utils.get_image_sizes(data_dict)
-            key = tuple(feats.shape)
+            up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
+            key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
             pending.setdefault(key, []).append((output_file, feats))
             if len(pending[key]) >= max(1, int(batch_size)):
-                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver)
+                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problem, key[1])
     for key in list(pending):
-        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver)
+        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problem, key[1])
     saver.close()
     _barrier()
 

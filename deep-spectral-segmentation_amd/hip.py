@@ -41,6 +41,8 @@ SYMBOLS = {
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dss_laplacian_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_int, c_void_p, c_size_t, c_void_p]),
+    "dss_symmetric_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                   c_int, c_void_p, c_size_t, c_void_p]),
     "dss_sign_rule": (c_int, [c_void_p, c_int, c_int, c_void_p]),
 }
 
@@ -250,9 +252,13 @@ def affinity_split(feats: torch.Tensor, normalize: bool = True, threshold_at_zer
     return w
 
 
+EIGS_NORMALIZED_LAPLACIAN, EIGS_AFFINITY_LM, EIGS_LAPLACIAN = 0, 1, 2
+
+
 def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0.0, max_restarts: int = 0,
-                   workspace: Optional[torch.Tensor] = None):
-    """packed ``W`` ``[B, affinity_elems(N)]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]``)."""
+                   workspace: Optional[torch.Tensor] = None, mode: int = EIGS_NORMALIZED_LAPLACIAN):
+    """packed ``W`` ``[B, affinity_elems(N)]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]``).
+    ``mode``: the problem solved on W (``dss_symmetric_eigs``); pairs come back in the solver's ranking order."""
     assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == affinity_elems(n)
     b = w.shape[0]
     lib = load_library()
@@ -263,10 +269,10 @@ def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0
     evecs = torch.empty((b, k, n), dtype=torch.float32, device=w.device)
     info = torch.zeros((b,), dtype=torch.int32, device=w.device)
     with _timed("laplacian_eigs", b=b, n=n, k=k, info=info):
-        _check(lib.dss_laplacian_eigs(_dev(w, "W"), b, n, k, _dev(evals, "evals"), _dev(evecs, "evecs"),
+        _check(lib.dss_symmetric_eigs(_dev(w, "W"), b, n, k, int(mode), _dev(evals, "evals"), _dev(evecs, "evecs"),
                                       _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
                                       workspace.numel() * workspace.element_size(), _stream()),
-               "dss_laplacian_eigs")
+               "dss_symmetric_eigs")
     return evals, evecs, info
 
 

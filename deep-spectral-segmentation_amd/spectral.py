@@ -19,11 +19,30 @@ class EigsNotConverged(RuntimeError):
     pass
 
 
+_PROBLEM_MODE = {"laplacian": hip.EIGS_NORMALIZED_LAPLACIAN, "laplacian_unnormalized": hip.EIGS_LAPLACIAN,
+                 "affinity": hip.EIGS_AFFINITY_LM, "affinity_svd": hip.EIGS_AFFINITY_LM}
+
+
+def _reference_order(problem: str, ev: torch.Tensor, vec: torch.Tensor):
+    """Arrange the solver's (ranking-ordered) pairs the way the reference saves them for this branch."""
+    if problem == "affinity":  # eigsh's ascending values as they are, vectors flipped to descending (extract.py:171-172)
+        order = torch.argsort(ev, dim=1)
+        vorder = order.flip(1)
+        return torch.gather(ev, 1, order), torch.gather(vec, 1, vorder[:, :, None].expand_as(vec))
+    if problem == "affinity_svd":  # singular values descending = sqrt of the eigenvalues of F F^T (extract.py:161-163)
+        order = torch.argsort(ev, dim=1, descending=True)
+        return (torch.gather(ev, 1, order).clamp_min(0).sqrt(),
+                torch.gather(vec, 1, order[:, :, None].expand_as(vec)))
+    return ev, vec
+
+
 @torch.no_grad()
 def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
                                  threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
                                  max_restarts: int = 0, max_bytes: int = 24 << 30, strict: bool = True,
-                                 affinity_mode: Optional[str] = None, retry: bool = True
+                                 affinity_mode: Optional[str] = None, retry: bool = True,
+                                 problem: str = "laplacian",
+                                 upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None
                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
     ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
@@ -31,6 +50,13 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     * eigenvalues ascending (``lambda_0 ~ 0``), eigenvectors D-orthonormal, sign rule applied - the
       conventions of the reference's ``.pth`` schema.
     * images are processed in chunks whose affinity matrices fit in ``max_bytes`` of HBM.
+    * ``problem``: ``"laplacian"`` (default: generalized ``(D-W)v = lambda D v``, extract.py:227),
+      ``"laplacian_unnormalized"`` (``lapnorm=False``, :232), ``"affinity"`` (largest-magnitude eigenpairs of W,
+      :166-172: eigenvalues ascending, eigenvectors in DESCENDING order - the reference's own quirk) or
+      ``"affinity_svd"`` (:160-163: top-K singular values / left singular vectors of the features, never thresholded).
+    * ``upsample``: ``((H_patch, W_patch), (H_lr, W_lr))`` - the reference's feature upsampling when
+      ``image_downsample_factor != patch_size`` (extract.py:179-188): the (already normalised) features are resized
+      bilinearly (``align_corners=False``) from the patch grid to the low-resolution pixel grid before the affinity.
     * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
       (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
@@ -46,8 +72,25 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     if affinity_mode not in ("split", "fp32"):
         raise ValueError(f"affinity_mode must be 'split' or 'fp32' (got {affinity_mode!r})")
     b, n, d = feats.shape
+    if upsample is not None:
+        (hp, wp), (hl, wl) = upsample
+        if hp * wp != n:
+            raise ValueError(f"upsample grid {hp}x{wp} does not match N={n}")
+        if normalize:
+            feats = hip.normalize_rows(feats.contiguous())
+        feats = torch.nn.functional.interpolate(feats.transpose(1, 2).reshape(b, d, hp, wp), size=(hl, wl),
+                                                mode="bilinear", align_corners=False)
+        feats = feats.reshape(b, d, hl * wl).transpose(1, 2).contiguous()
+        normalize, n = False, hl * wl  # extract.py normalises BEFORE the resize and not again after it
     if not K < n:
         raise ValueError(f"need K < N (K={K}, N={n})")
+    raw = problem.startswith("_raw_")  # internal: keep the solver's ranking order (used by the retry path)
+    if raw:
+        problem = problem[5:]
+    if problem not in _PROBLEM_MODE:
+        raise ValueError(f"unknown problem {problem!r}")
+    if problem == "affinity_svd":
+        threshold_at_zero = False  # the singular vectors of F are the eigenvectors of the UN-thresholded F F^T
     ld = hip.affinity_ld(n)
     per_image = hip.affinity_elems(n) * 4 + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
@@ -60,7 +103,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
             w = hip.affinity(f, threshold_at_zero)
         else:  # split-f16 (fp32-class accuracy, ~1e-7), HBM-bound; fused with the row normalisation
             w = hip.affinity_split(f, normalize, threshold_at_zero)
-        ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts)
+        ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts,
+                                           mode=_PROBLEM_MODE[problem])
         evals.append(ev), evecs.append(vec), infos.append(info)
         del w
     ev, vec, info = torch.cat(evals), torch.cat(evecs), torch.cat(infos)
@@ -74,8 +118,10 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         ev2, vec2, info2 = laplacian_eigs_from_features(
             feats[bad], K, normalize=normalize, threshold_at_zero=threshold_at_zero, ncv=64,
             tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60), max_bytes=max_bytes,
-            strict=False, affinity_mode=affinity_mode, retry=False)
+            strict=False, affinity_mode=affinity_mode, retry=False, problem="_raw_" + problem, upsample=None)
         ev[bad], vec[bad], info[bad] = ev2, vec2, info2
+    if not raw:
+        ev, vec = _reference_order(problem, ev, vec)
     if strict:
         bad = (info <= 0).nonzero().flatten().tolist()
         if bad:

@@ -119,6 +119,18 @@ int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, 
                        int32_t* info, int ncv, float tol, int max_restarts,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same solver on the other two problems of the reference's _extract_eig (same W layout, same outputs' shapes,
+ * pairs returned in the solver's ranking order; the sign rule is applied to every vector):
+ *   DSS_EIGS_NORMALIZED_LAPLACIAN (0)  = dss_laplacian_eigs                                   extract.py:227
+ *   DSS_EIGS_AFFINITY_LM          (1)  K eigenpairs of W of largest |value|, descending |value|  extract.py:171
+ *                                      (with W = F F^T un-thresholded: squared singular values / left singular
+ *                                       vectors of F, extract.py:161-163)
+ *   DSS_EIGS_LAPLACIAN            (2)  K smallest eigenpairs of D - W (lapnorm=False), ascending  extract.py:232 */
+enum { DSS_EIGS_NORMALIZED_LAPLACIAN = 0, DSS_EIGS_AFFINITY_LM = 1, DSS_EIGS_LAPLACIAN = 2 };
+int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode, float* eigenvalues, float* eigenvectors,
+                       int32_t* info, int ncv, float tol, int max_restarts,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a15: sign rule alone (extract/extract.py:238-240), in place on [rows, N] ----------------- */
 int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream);
 

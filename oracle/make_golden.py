@@ -325,6 +325,43 @@ def check_vit_against_hf(model_name="dino_vits16", seed=3, atol=2e-4):
     return e1, e2
 
 
+MODE_CASES = [  # name, kind, n, d, seed, hw, K, kwargs for the reference's _extract_eig
+    ("affinity_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="affinity")),
+    ("affinity_blobs_900", "blobs", 900, 384, 202, (30, 30), 5, dict(which_matrix="affinity")),
+    ("affinity_nothresh_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="affinity", threshold_at_zero=False)),
+    ("affinity_svd_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="affinity_svd")),
+    ("affinity_svd_random_900", "random", 900, 384, 201, (30, 30), 5, dict(which_matrix="affinity_svd")),
+    ("lapnorm_false_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="laplacian", lapnorm=False)),
+    ("lapnorm_false_blobs_900", "blobs", 900, 384, 202, (30, 30), 5, dict(which_matrix="laplacian", lapnorm=False)),
+    # feature upsampling (extract.py:179-188): P=16 features on an 8-pixel grid -> 2x bilinear, N_lr = 4 N
+    ("upsample8_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="laplacian", image_downsample_factor=8)),
+    ("upsample8_blobs_23x31", "blobs", 713, 384, 401, (23, 31), 4, dict(which_matrix="laplacian", image_downsample_factor=8)),
+]
+
+
+def make_mode_goldens(ref):
+    """The reference's other _extract_eig branches (extract.py:159-172 affinity / affinity_svd, :230-234 lapnorm=False)."""
+    for name, kind, n, d, seed, hw, K, kw in MODE_CASES:
+        feats = synthetic.synthetic_features(kind, n, d, seed, hw)
+        with tempfile.TemporaryDirectory() as tmp:
+            fdir, odir = Path(tmp) / "f", Path(tmp) / "o"
+            fdir.mkdir(), odir.mkdir()
+            torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": f"{name}.jpg",
+                        "id": name, "model_name": "dino_vits16", "patch_size": 16,
+                        "shape": (1, 3, hw[0] * 16, hw[1] * 16)}, fdir / f"{name}.pth")
+            ref._extract_eig((0, str(fdir / f"{name}.pth")), K=K, images_root="", output_dir=str(odir),
+                             image_color_lambda=0.0, **kw)
+            out = torch.load(odir / f"{name}.pth", map_location="cpu", weights_only=False)
+        ev, evec = out["eigenvalues"], out["eigenvectors"]
+        ev_is_numpy = isinstance(ev, np.ndarray)
+        ev = np.asarray(ev)
+        np.savez_compressed(GOLDEN / f"modes_{name}.npz", kind=kind, n=n, d=d, seed=seed, hw=np.array(hw), K=K,
+                            kwargs=np.array(repr(kw)), eigenvalues=ev, eigenvalues_dtype=str(ev.dtype),
+                            eigenvalues_is_numpy=ev_is_numpy, eigenvectors=evec.numpy(),
+                            eigenvectors_dtype=str(evec.dtype))
+        print(f"[golden] modes_{name}: ev({'np' if ev_is_numpy else 'torch'},{ev.dtype})={ev[:5]} vec{tuple(evec.shape)} {evec.dtype}")
+
+
 def make_single_region_golden(ref):
     """Reference extract_single_region_segmentations (extract.py:383-426) on a synthetic feature/eig pair."""
     from PIL import Image
@@ -356,6 +393,7 @@ def main():
     make_feature_goldens(ref)
     make_eig_goldens(ref)
     make_single_region_golden(ref)
+    make_mode_goldens(ref)
 
 
 if __name__ == "__main__":

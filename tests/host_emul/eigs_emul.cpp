@@ -13,12 +13,12 @@
 // W: packed upper-triangular 64x64 tiles (csrc/eigs_core.h wsym_*), wsym_floats(ld) floats per image.
 extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int K, float* eigenvalues,
                                        float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
-                                       int max_restarts) {
+                                       int max_restarts, int mode) {
   using namespace dss;
   if (ncv > EIGS_MAX_NCV) ncv = EIGS_MAX_NCV;
   if (ncv > N) ncv = N;
   EigsParams P;
-  P.N = N; P.ld = ld; P.K = K; P.ncv = ncv; P.keep = keep; P.max_restarts = max_restarts; P.tol = tol;
+  P.N = N; P.ld = ld; P.K = K; P.ncv = ncv; P.keep = keep; P.max_restarts = max_restarts; P.tol = tol; P.mode = mode;
   const EigsLds L = eigs_lds_layout(ld, ncv);
   std::vector<unsigned char> lds(L.total + 64);
   unsigned char* lp = lds.data();

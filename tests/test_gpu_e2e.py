@@ -205,3 +205,22 @@ def test_cli_two_ranks_shard_round_robin(tmp_path):
         e2 = torch.load(tmp_path / "eigs2" / n, weights_only=True)
         check_eigs(e2["eigenvectors"].numpy(), e2["eigenvalues"].numpy(), e1["eigenvectors"].numpy(),
                    e1["eigenvalues"].numpy(), what=n)
+
+
+def test_cli_other_which_matrix_branches(tmp_path):
+    """extract_eigs --which_matrix affinity / affinity_svd and --lapnorm False write the reference's schemas."""
+    feats = synthetic.synthetic_features("blobs", 196, 384, 102, (14, 14))
+    (tmp_path / "f").mkdir()
+    torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": "x.jpg", "id": "x",
+                "model_name": "dino_vits16", "patch_size": 16, "shape": (1, 3, 224, 224)}, tmp_path / "f" / "x.pth")
+    for tag, extra in [("aff", ["--which_matrix", "affinity"]), ("svd", ["--which_matrix", "affinity_svd"]),
+                       ("unn", ["--lapnorm", "False"])]:
+        extract.main(["extract_eigs", "--images_root", "", "--features_dir", str(tmp_path / "f"), "--output_dir",
+                      str(tmp_path / tag), "--K", "5", *extra])
+        d = torch.load(tmp_path / tag / "x.pth", weights_only=False)
+        assert d["eigenvectors"].shape == (5, 196) and d["eigenvectors"].dtype == torch.float32
+        if tag == "aff":
+            assert isinstance(d["eigenvalues"], np.ndarray) and d["eigenvalues"].dtype == np.float32
+            assert np.all(np.diff(d["eigenvalues"]) > 0)
+        else:
+            assert torch.is_tensor(d["eigenvalues"]) and d["eigenvalues"].dtype == torch.float32

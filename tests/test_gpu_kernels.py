@@ -245,3 +245,38 @@ def test_sign_rule_kernel():
     g = torch.Generator().manual_seed(0)
     big = torch.randn(6, 901, generator=g)
     assert torch.equal(hip.sign_rule_(big.clone().to(DEV)).cpu(), spectral_ref.ref_sign_rule(big.clone()))
+
+
+# ----------------------------------------------------------------------------- the other _extract_eig branches
+MODE_FILES = sorted(glob.glob(str(HERE / "golden" / "modes_*.npz")))
+
+
+@pytest.mark.parametrize("path", MODE_FILES, ids=lambda p: p.split("modes_")[-1][:-4])
+def test_other_branches_match_reference_goldens(path):
+    """which_matrix='affinity' / 'affinity_svd' and lapnorm=False through the same Lanczos kernel, against the
+    reference's own outputs (ordering quirks included: 'affinity' saves ascending values with DESCENDING vectors)."""
+    g = np.load(path)
+    feats = synthetic.synthetic_features(str(g["kind"]), int(g["n"]), int(g["d"]), int(g["seed"]), tuple(g["hw"]))
+    kw = eval(str(g["kwargs"]))
+    K = int(g["K"])
+    problem = kw["which_matrix"] if kw["which_matrix"] != "laplacian" else (
+        "laplacian" if kw.get("lapnorm", True) else "laplacian_unnormalized")
+    up = None
+    if "image_downsample_factor" in kw:  # P = 16 features resized to the (16 / f) x finer grid (extract.py:179-188)
+        hp, wp = (int(v) for v in g["hw"])
+        f = 16 // kw["image_downsample_factor"]
+        up = ((hp, wp), (hp * f, wp * f))
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K, problem=problem,
+                                                          threshold_at_zero=kw.get("threshold_at_zero", True),
+                                                          upsample=up)
+    assert info.item() > 0
+    lam, v = ev[0].cpu().numpy().astype(np.float64), vec[0].cpu().numpy()
+    ref_lam, ref_v = np.asarray(g["eigenvalues"], np.float64), g["eigenvectors"]
+    scale = max(1.0, np.abs(ref_lam).max())
+    tol = dict(lam_tol=2e-5 * scale, gap_tol=1e-4 * scale)
+    if problem == "affinity":        # values ascending, vectors descending: flip the vectors to a common order
+        check_eigs(v[::-1], lam, ref_v[::-1], ref_lam, what=path, **tol)
+    elif problem == "affinity_svd":  # both descending: flip both for the ascending-order checker
+        check_eigs(v[::-1], lam[::-1], ref_v[::-1], ref_lam[::-1], what=path, **tol)
+    else:
+        check_eigs(v, lam, ref_v, ref_lam, what=path, **tol)

@@ -23,7 +23,7 @@ def emul(tmp_path_factory):
                     str(HERE / "host_emul" / "eigs_emul.cpp")], check=True)
     lib = ctypes.CDLL(str(out))
     lib.dss_emul_laplacian_eigs.argtypes = [FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, FP, FP, IP,
-                                            ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int]
     return lib
 
 
@@ -37,11 +37,12 @@ def pack_sym(w, ld):
     return np.ascontiguousarray(np.concatenate(tiles))
 
 
-def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60):
+def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, threshold=True):
     x = feats / np.maximum(np.linalg.norm(feats, axis=1, keepdims=True), 1e-12)
     x = x.astype(np.float32)
     w = x @ x.T
-    w = w * (w > 0)
+    if threshold:
+        w = w * (w > 0)
     n = w.shape[0]
     ld = (n + 63) // 64 * 64
     wp = pack_sym(w, ld)
@@ -49,7 +50,7 @@ def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60):
     keep = keep or (ncv + K) // 2
     ev, vec, info = np.zeros(K, np.float32), np.zeros((K, n), np.float32), np.zeros(1, np.int32)
     lib.dss_emul_laplacian_eigs(wp.ctypes.data_as(FP), 1, n, ld, K, ev.ctypes.data_as(FP), vec.ctypes.data_as(FP),
-                                info.ctypes.data_as(IP), ncv, keep, tol, max_restarts)
+                                info.ctypes.data_as(IP), ncv, keep, tol, max_restarts, mode)
     return ev, vec, int(info[0])
 
 
@@ -83,3 +84,53 @@ def test_kernel_logic_restart_budget_reports_nonconvergence(emul):
     feats, K, *_ = golden_case([p for p in CASES if "g2_random_900" in p][0])
     lam, vec, info = run_emul(emul, feats, K, max_restarts=1)
     assert info < 0 and np.all(np.isfinite(vec))
+
+
+# ---- the other _extract_eig branches (extract.py:159-172, :230-234): same kernel, other operator / selection modes ----
+MODE_FILES = [p for p in sorted(glob.glob(str(HERE / "golden" / "modes_*.npz"))) if "upsample" not in p]
+
+
+def mode_outputs_like_reference(kind, values, vectors):
+    """Arrange (values, vectors) as the reference saves them for this branch (values/vectors arrive in the kernel's
+    ranking order: descending theta, or descending |theta| for the affinity modes)."""
+    values, vectors = np.asarray(values, np.float64), np.asarray(vectors)
+    if kind == "affinity":          # eigsh ascending values kept as-is, eigenvectors FLIPPED to descending (:171-172)
+        order = np.argsort(values)
+        return values[order], vectors[order][::-1]
+    if kind == "affinity_svd":      # singular values descending, left singular vectors (:161-163)
+        order = np.argsort(-values)
+        return np.sqrt(np.maximum(values[order], 0.0)), vectors[order]
+    return values, vectors          # lapnorm=False: eigenvalues ascending (:232-235)
+
+
+def check_mode_against_golden(g, values, vectors, what):
+    kw = eval(str(g["kwargs"]))     # fixture metadata written by oracle/make_golden.py
+    kind = kw["which_matrix"] if kw["which_matrix"] != "laplacian" else "laplacian_unnormalized"
+    lam, vec = mode_outputs_like_reference(kind, values, vectors)
+    ref_lam, ref_vec = np.asarray(g["eigenvalues"], np.float64), g["eigenvectors"]
+    scale = max(1.0, np.abs(ref_lam).max())
+    if kind == "affinity":          # vectors are in the opposite order of the values: compare in a common order
+        check_eigs(vec[::-1], lam, ref_vec[::-1], ref_lam, what=what, lam_tol=2e-5 * scale, gap_tol=1e-4 * scale)
+    elif kind == "affinity_svd":
+        check_eigs(vec[::-1], lam[::-1], ref_vec[::-1], ref_lam[::-1], what=what, lam_tol=2e-5 * scale,
+                   gap_tol=1e-4 * scale)
+    else:
+        check_eigs(vec, lam, ref_vec, ref_lam, what=what, lam_tol=2e-5 * scale, gap_tol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("path", MODE_FILES, ids=lambda p: p.split("modes_")[-1][:-4])
+def test_kernel_logic_other_branches_match_reference_goldens(emul, path):
+    g = np.load(path)
+    feats = __import__("dss_amd").synthetic.synthetic_features(str(g["kind"]), int(g["n"]), int(g["d"]), int(g["seed"]),
+                                                              tuple(g["hw"]))
+    kw = eval(str(g["kwargs"]))
+    K = int(g["K"])
+    if kw["which_matrix"] == "affinity":
+        mode, thr = 1, kw.get("threshold_at_zero", True)
+    elif kw["which_matrix"] == "affinity_svd":
+        mode, thr = 1, False
+    else:
+        mode, thr = 2, True
+    values, vectors, info = run_emul(emul, feats, K, mode=mode, threshold=thr)
+    assert info > 0, info
+    check_mode_against_golden(g, values, vectors, path)

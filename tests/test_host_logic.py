@@ -57,12 +57,20 @@ def test_cli_parsing_matches_fire_conventions():
 
 def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
-        extract._check_eig_options("affinity", True, 0.0, None, 16)
+        extract._check_eig_options("affinity_torch", True, 0.0, None, 16)
     with pytest.raises(NotImplementedError):
         extract._check_eig_options("laplacian", True, 10.0, None, 16)
-    with pytest.raises(NotImplementedError):
-        extract._check_eig_options("laplacian", False, 0.0, None, 16)
-    extract._check_eig_options("matting_laplacian", True, 0.0, 16, 16)
+    assert extract._check_eig_options("laplacian", True, 0.0, 8, 16) == "laplacian"   # upsampling is built
+    dd = {"patch_size": 16, "shape": (1, 3, 375, 500)}
+    assert extract._upsample_spec(dd, "laplacian", 8) == ((23, 31), (46, 62))
+    assert extract._upsample_spec(dd, "laplacian", 16) is None and extract._upsample_spec(dd, "laplacian", None) is None
+    assert extract._upsample_spec(dd, "affinity", 8) is None
+    with pytest.raises(ValueError):
+        extract._check_eig_options("bogus", True, 0.0, None, 16)
+    assert extract._check_eig_options("matting_laplacian", True, 0.0, 16, 16) == "laplacian"
+    assert extract._check_eig_options("laplacian", False, 0.0, None, 16) == "laplacian_unnormalized"
+    assert extract._check_eig_options("affinity", True, 10.0, None, 16) == "affinity"
+    assert extract._check_eig_options("affinity_svd", True, 0.0, None, 16) == "affinity_svd"
 
 
 def test_dataset_order_and_image_sizes(tmp_path):
