@@ -287,7 +287,8 @@ __device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& mc, fl
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
-                                                           int heads, int nb, int nqb, float scale_log2) {
+                                                           int heads, int nb, int nqb, float scale_log2,
+                                                           int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
   __shared__ __attribute__((aligned(16))) T Ks[2][64 * KLD];
@@ -313,8 +314,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
     }
   }
   const int head = group % heads, b = group / heads;
-  const long rs = 3L * heads * DH;                                  // qkv row stride (halves)
-  const T* base = qkv + (long)b * Tn * rs + (long)head * DH;       // q of token 0; k at +heads*DH, v at +2*heads*DH
+  // interleaved qkv [B, T, 3, h, 64]: row stride 3*h*64, k at +h*64, v at +2*h*64 from q.
+  // planar qkv [3*h][B*T][64] (what dss_linear_k384 writes with DSS_PLANAR64): every (q|k|v, head) is a plane of
+  // contiguous 128-byte rows, so the K/V tiles of one (image, head) are contiguous 8 KB runs.
+  const long plane = (long)nb * Tn * DH;
+  const long rs = planar ? DH : 3L * heads * DH;                    // row stride (halves)
+  const long koff = planar ? heads * plane : (long)heads * DH;      // q -> k ; q -> v is twice that
+  const T* base = planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
   const int q0 = qblk * 256 + wave * 64;
   const bool active = q0 < Tn;                                      // wave-uniform
 
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
       const int key = kt * 64 + srow0 + 32 * j;
       if (key < Tn) {
         const T* p = base + (long)key * rs + scol;
-        kreg[j] = *reinterpret_cast<const V8*>(p + (long)heads * DH);
-        vreg[j] = *reinterpret_cast<const V8*>(p + 2L * heads * DH);
+        kreg[j] = *reinterpret_cast<const V8*>(p + koff);
+        vreg[j] = *reinterpret_cast<const V8*>(p + 2 * koff);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { kreg[j][i] = (T)0.f; vreg[j][i] = (T)0.f; }
@@ -437,11 +443,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
 
 template <class T>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, void* ws,
-                             hipStream_t s, int impl) {
+                             hipStream_t s, int impl, int planar) {
   if (impl != 1) {  // v2 (default): LDS-staged, no pack pass, workspace unused
     const int nqb = ceil_div(Tn, 256);
     hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(256), 0, s, (const T*)qkv,
-                       (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f);
+                       (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
     return;
   }
   const int Tp = attn_tp(Tn);
@@ -470,9 +476,11 @@ extern "C" size_t dss_attention_workspace_bytes(int B, int T, int heads) {
   return (size_t)3 * B * heads * dss::attn_tp(T) * dss::DH * 2;
 }
 
-extern "C" int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale,
+extern "C" int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, int heads, float scale,
                                  int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   DSS_REQUIRE(qkv && out, "dss_attention_fwd: null pointer");
+  DSS_REQUIRE(qkv_layout == DSS_ROW_MAJOR || qkv_layout == DSS_PLANAR64,
+              "dss_attention_fwd: qkv_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", qkv_layout);
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
   DSS_REQUIRE(B <= 65535 && heads <= 65535, "dss_attention_fwd: B and heads must be <= 65535");
   const size_t need = dss_attention_workspace_bytes(B, T, heads);
@@ -480,9 +488,11 @@ extern "C" int dss_attention_fwd(const void* qkv, void* out, int B, int T, int h
     return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const int impl = dss::attention_impl();
+  const int planar = qkv_layout == DSS_PLANAR64;
+  DSS_REQUIRE(!(planar && impl == 1), "dss_attention_fwd: DSS_ATTENTION_IMPL=1 reads interleaved qkv only");
   switch (dtype) {
-    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;
-    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s, impl); break;
+    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s, impl, planar); break;
+    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s, impl, planar); break;
     default: return dss::fail(DSS_ERR_BAD_ARG, "dss_attention_fwd: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
   }
   DSS_CHECK_LAUNCH("attention");

@@ -29,7 +29,8 @@ template <int VPL, class TO, class TR, bool HAS_RES>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const TR* __restrict__ res,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
-                                                        TO* __restrict__ y, int rows, int D, float eps) {
+                                                        TO* __restrict__ y, int rows, int D, float eps,
+                                                        long res_ld, long res_plane) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
       if (c < nvec) {
         v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
         if (HAS_RES) {
-          v[i] += pack4<TR>::load(res + row * D + 4 * c);
+          // vector c = columns 4c .. 4c+3 = 64-column group c >> 4, offset 4 (c & 15).  Row-major residual:
+          // (res_ld, res_plane) = (D, 64); planar [D/64][rows][64] (dss_linear_k384's DSS_PLANAR64): (64, 64 rows)
+          v[i] += pack4<TR>::load(res + (c >> 4) * res_plane + row * res_ld + 4 * (c & 15));
           *reinterpret_cast<f32x4*>(xr + 4 * c) = v[i];
         }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -77,55 +80,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 
 template <int VPL, class TO, class TR, bool HAS_RES>
 static void launch_ln(float* x, const void* res, const float* gamma, const float* beta, void* y, int rows,
-                      int D, float eps, hipStream_t s) {
+                      int D, float eps, int planar, hipStream_t s) {
   int blocks = ceil_div(rows, 4);
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL((layernorm_kernel<VPL, TO, TR, HAS_RES>), dim3(blocks), dim3(256), 0, s, x,
-                     (const TR*)res, gamma, beta, (TO*)y, rows, D, eps);
+                     (const TR*)res, gamma, beta, (TO*)y, rows, D, eps, planar ? 64L : (long)D,
+                     planar ? 64L * rows : 64L);
 }
 
 template <class TO, class TR, bool HAS_RES>
 static void dispatch_vpl(float* x, const void* res, const float* gamma, const float* beta, void* y, int rows,
-                         int D, float eps, hipStream_t s) {
+                         int D, float eps, int planar, hipStream_t s) {
   const int vpl = ceil_div(D, 256);
   switch (vpl) {
-    case 1: launch_ln<1, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, s); break;
-    case 2: launch_ln<2, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, s); break;
-    case 3: launch_ln<3, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, s); break;
-    case 4: launch_ln<4, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, s); break;
-    default: launch_ln<8, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, s); break;
+    case 1: launch_ln<1, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, planar, s); break;
+    case 2: launch_ln<2, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, planar, s); break;
+    case 3: launch_ln<3, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, planar, s); break;
+    case 4: launch_ln<4, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, planar, s); break;
+    default: launch_ln<8, TO, TR, HAS_RES>(x, res, gamma, beta, y, rows, D, eps, planar, s); break;
   }
 }
 
 template <class TO>
 static int dispatch_res(float* x, const void* res, int res_dtype, const float* gamma, const float* beta,
-                        void* y, int rows, int D, float eps, hipStream_t s) {
+                        void* y, int rows, int D, float eps, int planar, hipStream_t s) {
   if (!res) {
-    dispatch_vpl<TO, float, false>(x, nullptr, gamma, beta, y, rows, D, eps, s);
+    dispatch_vpl<TO, float, false>(x, nullptr, gamma, beta, y, rows, D, eps, 0, s);
     return DSS_OK;
   }
   switch (res_dtype) {
-    case DSS_F32: dispatch_vpl<TO, float, true>(x, res, gamma, beta, y, rows, D, eps, s); return DSS_OK;
-    case DSS_F16: dispatch_vpl<TO, f16, true>(x, res, gamma, beta, y, rows, D, eps, s); return DSS_OK;
-    case DSS_BF16: dispatch_vpl<TO, bf16, true>(x, res, gamma, beta, y, rows, D, eps, s); return DSS_OK;
+    case DSS_F32: dispatch_vpl<TO, float, true>(x, res, gamma, beta, y, rows, D, eps, planar, s); return DSS_OK;
+    case DSS_F16: dispatch_vpl<TO, f16, true>(x, res, gamma, beta, y, rows, D, eps, planar, s); return DSS_OK;
+    case DSS_BF16: dispatch_vpl<TO, bf16, true>(x, res, gamma, beta, y, rows, D, eps, planar, s); return DSS_OK;
   }
   return fail(DSS_ERR_BAD_ARG, "dss_layernorm_fwd: unsupported res_dtype %d", res_dtype);
 }
 
 }  // namespace dss
 
-extern "C" int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, const float* gamma,
+extern "C" int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, int res_layout, const float* gamma,
                                  const float* beta, void* y, int out_dtype, int rows, int D, float eps,
                                  void* stream) {
   DSS_REQUIRE(x && gamma && beta && y, "dss_layernorm_fwd: null pointer");
   DSS_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048,
               "dss_layernorm_fwd: need rows > 0, D %% 4 == 0, D <= 2048 (rows=%d D=%d)", rows, D);
+  DSS_REQUIRE(res_layout == DSS_ROW_MAJOR || (res_layout == DSS_PLANAR64 && D % 64 == 0),
+              "dss_layernorm_fwd: res_layout must be DSS_ROW_MAJOR, or DSS_PLANAR64 with D %% 64 == 0 (got %d, D=%d)",
+              res_layout, D);
+  const int planar = residual && res_layout == DSS_PLANAR64;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   switch (out_dtype) {
-    case DSS_F32: rc = dss::dispatch_res<float>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, s); break;
-    case DSS_F16: rc = dss::dispatch_res<dss::f16>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, s); break;
-    case DSS_BF16: rc = dss::dispatch_res<dss::bf16>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, s); break;
+    case DSS_F32: rc = dss::dispatch_res<float>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, planar, s); break;
+    case DSS_F16: rc = dss::dispatch_res<dss::f16>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, planar, s); break;
+    case DSS_BF16: rc = dss::dispatch_res<dss::bf16>(x, residual, res_dtype, gamma, beta, y, rows, D, eps, planar, s); break;
     default: return dss::fail(DSS_ERR_BAD_ARG, "dss_layernorm_fwd: unsupported out_dtype %d", out_dtype);
   }
   if (rc != DSS_OK) return rc;

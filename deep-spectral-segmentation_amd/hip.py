@@ -26,11 +26,12 @@ SYMBOLS = {
     "dss_target_arch": (c_char_p, []),
     "dss_preprocess_chw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dss_preprocess_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dss_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+    "dss_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "dss_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "dss_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
+    "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
                                   c_void_p]),
+    "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -148,9 +149,19 @@ def preprocess_patchify(img_u8: torch.Tensor, patch: int, dtype: torch.dtype) ->
 
 
 # --------------------------------------------------------------------------------------- ViT kernels
+ROW_MAJOR, PLANAR64 = 0, 1      # activation layouts (include/dss_hip.h)
+
+
+def planar_to_rows(t: torch.Tensor) -> torch.Tensor:
+    """``[D/64, rows, 64]`` (DSS_PLANAR64) -> row-major ``[rows, D]`` (a copy; tests and diagnostics)."""
+    return t.permute(1, 0, 2).reshape(t.shape[1], t.shape[0] * 64)
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype,
-              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``LN(x (+ residual))`` over the last dim; with ``residual`` the sum is written back into ``x``."""
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              residual_planar: bool = False) -> torch.Tensor:
+    """``LN(x (+ residual))`` over the last dim; with ``residual`` the sum is written back into ``x``.
+    ``residual_planar``: the residual is ``[D/64, rows, 64]`` as written by ``linear_k384(..., planar=True)``."""
     assert x.dtype == torch.float32
     d = x.shape[-1]
     rows = x.numel() // d
@@ -158,9 +169,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     rp, rc = (0, 0) if residual is None else (_dev(residual, "residual"), dtype_code(residual.dtype))
     if residual is not None:
-        assert residual.shape == x.shape
+        assert residual.shape == ((d // 64, rows, 64) if residual_planar else x.shape)
+    layout = PLANAR64 if (residual is not None and residual_planar) else ROW_MAJOR
     with _timed("layernorm", rows=rows, d=d, res=residual is not None, out_bytes=out.element_size()):
-        _check(load_library().dss_layernorm_fwd(_dev(x, "x"), rp, rc, _dev(gamma, "gamma"), _dev(beta, "beta"),
+        _check(load_library().dss_layernorm_fwd(_dev(x, "x"), rp, rc, layout, _dev(gamma, "gamma"), _dev(beta, "beta"),
                                                 _dev(out, "out"), dtype_code(out.dtype), rows, d, float(eps),
                                                 _stream()), "dss_layernorm_fwd")
     return out
@@ -171,10 +183,15 @@ def attention_workspace_bytes(b: int, t: int, heads: int) -> int:
 
 
 def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``qkv`` ``[B, T, 3*heads*64]`` (fp16/bf16) -> ``[B, T, heads*64]``."""
-    b, t, c3 = qkv.shape
-    assert c3 == 3 * heads * 64, "head dim must be 64"
+              out: Optional[torch.Tensor] = None, planar_bt: Optional[tuple] = None) -> torch.Tensor:
+    """``qkv`` ``[B, T, 3*heads*64]`` (fp16/bf16) -> ``[B, T, heads*64]``.  With ``planar_bt=(B, T)`` ``qkv`` is the
+    DSS_PLANAR64 form ``[3*heads, B*T, 64]`` written by ``linear_k384(..., planar=True)``."""
+    if planar_bt is None:
+        b, t, c3 = qkv.shape
+        assert c3 == 3 * heads * 64, "head dim must be 64"
+    else:
+        b, t = planar_bt
+        assert tuple(qkv.shape) == (3 * heads, b * t, 64), "planar qkv must be [3*heads, B*T, 64]"
     need = attention_workspace_bytes(b, t, heads)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
@@ -182,9 +199,26 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[t
     if out is None:
         out = torch.empty((b, t, heads * 64), dtype=qkv.dtype, device=qkv.device)
     with _timed("attention", b=b, t=t, heads=heads):
-        _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), _dev(out, "out"), b, t, heads, float(scale),
+        _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), ROW_MAJOR if planar_bt is None else PLANAR64,
+                                                _dev(out, "out"), b, t, heads, float(scale),
                                                 dtype_code(qkv.dtype), wptr, wbytes, _stream()),
                "dss_attention_fwd")
+    return out
+
+
+def linear_k384(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
+                planar: bool = False) -> torch.Tensor:
+    """``x [..., 384] @ weight[N, 384]^T + bias`` (optionally + exact erf-GELU) on the K-resident MFMA kernel.
+    Returns ``[..., N]``, or with ``planar`` the DSS_PLANAR64 form ``[N/64, rows, 64]``."""
+    assert x.shape[-1] == 384 and weight.shape[1] == 384 and x.dtype == weight.dtype == bias.dtype
+    n = weight.shape[0]
+    m = x.numel() // 384
+    shape = (n // 64, m, 64) if planar else (*x.shape[:-1], n)
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    with _timed("linear_k384", m=m, n=n, gelu=gelu):
+        _check(load_library().dss_linear_k384(_dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(out, "out"),
+                                              m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
+                                              _stream()), "dss_linear_k384")
     return out
 
 

@@ -18,6 +18,8 @@ loads unchanged.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from pathlib import Path
 from typing import Dict, Optional, Tuple
@@ -100,6 +102,9 @@ class DinoViT:
         # the TANH approximation (measured: 3.6e-7 from tanh-GELU, 4.7e-4 from erf-GELU).  It is NOT DINO's function:
         # opt-in only, never used for the reported numbers.
         self.gelu = gelu
+        # qkv / attn.proj of the D = 384 models on the K-resident kernel (dss_linear_k384) with planar outputs that
+        # the attention and LayerNorm kernels read in place; DSS_LINEAR_K384=0 keeps the library GEMMs (A/B switch)
+        self.linear_k384 = os.environ.get("DSS_LINEAR_K384", "1") not in ("0", "")
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -184,13 +189,21 @@ class DinoViT:
         ws = self._attn_workspace(b, t)
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
+        k384 = self.linear_k384 and d == 384   # K-resident GEMMs (planar outputs) for the D = 384 models
         for i in range(wb):
             blk = self.blocks[i]
             hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
-            qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
-            o = hip.attention(qkv, heads, self.scale, workspace=ws)
-            pending = F.linear(o, blk["proj_w"], blk["proj_b"])
-            hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
+            if k384:
+                qkv = hip.linear_k384(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)       # [3h, B*T, 64]
+                o = hip.attention(qkv, heads, self.scale, workspace=ws, planar_bt=(b, t))
+                pending = hip.linear_k384(o, blk["proj_w"], blk["proj_b"], planar=True)    # [6, B*T, 64]
+                hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
+                                     residual_planar=True)
+            else:
+                qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
+                o = hip.attention(qkv, heads, self.scale, workspace=ws)
+                pending = F.linear(o, blk["proj_w"], blk["proj_b"])
+                hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
             if self.gelu == "erf":
                 f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
             else:

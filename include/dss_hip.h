@@ -25,9 +25,17 @@
 extern "C" {
 #endif
 
-#define DSS_ABI_VERSION 1
+#define DSS_ABI_VERSION 2
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
+
+/* Layout of a [rows, D] half-precision activation (D % 64 == 0 for DSS_PLANAR64):
+ *   DSS_ROW_MAJOR : element (r, c) at r * D + c                       - what torch.nn.Linear produces;
+ *   DSS_PLANAR64  : element (r, c) at (c / 64) * rows * 64 + r * 64 + c % 64, i.e. [D/64][rows][64] - every
+ *                   64-column group (one attention head) is a plane of contiguous 128-byte rows.  Written by
+ *                   dss_linear_k384, read by dss_attention_fwd (qkv) and dss_layernorm_fwd (residual): a wave's
+ *                   64 x 64 output tile is one contiguous 8 KB run instead of 64 scattered 128-byte lines. */
+enum { DSS_ROW_MAJOR = 0, DSS_PLANAR64 = 1 };
 
 enum {
   DSS_OK = 0,
@@ -60,19 +68,28 @@ int dss_preprocess_patchify(const uint8_t* img_u8, void* out, int B, int H, int 
  * x: [rows, D] f32.  y: [rows, D] in out_dtype.  D % 4 == 0, D <= 2048.
  * If `residual` != NULL (dtype `res_dtype`, [rows, D]) the kernel first does x += residual
  * IN PLACE (the block's `x = x + attn(...)` / `x = x + mlp(...)`) and normalises the sum. */
-int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, const float* gamma,
+int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, int res_layout, const float* gamma,
                       const float* beta, void* y, int out_dtype, int rows, int D, float eps,
                       void* stream);
 
 /* ---- a6'': multi-head self-attention (DINO Attention.forward, heads of 64) ----------------
- * qkv: [B, T, 3, heads, 64] in `dtype` (the qkv Linear's output, untouched);
+ * qkv: [B, T, 3, heads, 64] in `dtype` (the qkv Linear's output, untouched) when qkv_layout == DSS_ROW_MAJOR, or
+ *      the same [B*T, 3*heads*64] matrix in DSS_PLANAR64 layout (plane index = which * heads + head);
  * out: [B, T, heads*64] in `dtype`  = softmax(q k^T * scale) v, heads re-interleaved as the
  * reference's `.transpose(1, 2).reshape(B, T, C)`.  fp32 accumulation and softmax statistics.
  * workspace: dss_attention_workspace_bytes(B, T, heads) bytes - 0 (pass NULL) for the default LDS-staged
  * kernel, which reads qkv in place; packed Q/K/V^T panels for the DSS_ATTENTION_IMPL=1 variant. */
 size_t dss_attention_workspace_bytes(int B, int T, int heads);
-int dss_attention_fwd(const void* qkv, void* out, int B, int T, int heads, float scale, int dtype,
+int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, int heads, float scale, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a6: Linear layers with a 384-wide reduction (qkv / attn.proj / mlp.fc1 of dino_vits16, dino_vits8) -------
+ * C[M, N] = A[M, 384] . W[N, 384]^T + bias[N], optionally followed by the exact (erf) GELU of DINO's Mlp
+ * (replaces torch.nn.Linear / nn.GELU inside DINO's Block; reached from extract/extract.py:94).
+ * A (row-major), W, bias, C in `dtype` (DSS_F16 / DSS_BF16), fp32 accumulation; N % 64 == 0, N <= 2048.
+ * out_layout: DSS_ROW_MAJOR or DSS_PLANAR64 (see above).  K-resident MFMA kernel (linear384.hip). */
+int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
+                    int dtype, void* stream);
 
 /* ---- a10: row L2 normalisation -------------------------------------------------------------
  * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */

@@ -1,0 +1,34 @@
+"""Same-process A/B: K-resident linear kernel vs torch (hipBLASLt) for the D=384 GEMMs, plus correctness."""
+import os, sys, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import dss_amd
+from dss_amd import hip
+from dss_amd.vit import setup_gemm_tuning
+setup_gemm_tuning()
+torch.manual_seed(0)
+M = 256 * 901  # multiple of the 256-row workgroup tile
+x = (torch.randn(M, 384, device='cuda') * 1.0).half()
+if os.environ.get("PROF"):
+    w = (torch.randn(1152, 384, device='cuda') * 0.05).half(); b = (torch.randn(1152, device='cuda') * 0.1).half()
+    for _ in range(5): hip.linear_k384(x, w, b, False)
+    torch.cuda.synchronize(); sys.exit(0)
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(n): fn()
+    en.record(); torch.cuda.synchronize()
+    return st.elapsed_time(en) / n * 1e3
+for name, N, gelu in [("qkv", 1152, False), ("proj", 384, False), ("fc1+gelu", 1536, True), ("fc1", 1536, False)][:int(os.environ.get("NCASE", 4))]:
+    w = (torch.randn(N, 384, device='cuda') * 0.05).half(); b = (torch.randn(N, device='cuda') * 0.1).half()
+    mchk = 4096 + 77                      # not a multiple of the 512-row workgroup tile: exercises the ragged tail
+    ref = F.linear(x[:mchk].float(), w.float(), b.float())
+    if gelu: ref = F.gelu(ref)
+    guard = torch.full((mchk + 8, N), 7.0, device='cuda', dtype=x.dtype)
+    out = hip.linear_k384(x[:mchk], w, b, gelu).float()
+    lib = hip.load_library(); assert lib is not None
+    err = (out - ref).abs().max().item(); scale = ref.abs().max().item()
+    t_lib = timeit((lambda: F.gelu(F.linear(x, w, b))) if gelu else (lambda: F.linear(x, w, b)))
+    t_own = timeit(lambda: hip.linear_k384(x, w, b, gelu))
+    fl = 2.0 * M * N * 384
+    print(f"{name:9s} N={N:4d}: torch {t_lib:7.1f} us ({fl/t_lib/1e6:6.0f} TF/s)   k384 {t_own:7.1f} us ({fl/t_own/1e6:6.0f} TF/s)   max err {err:.2e} (|ref|max {scale:.1f})")

@@ -76,6 +76,78 @@ def test_layernorm_fused_residual(res_dtype):
     assert (out.double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
 
 
+def _to_planar(t2d):
+    """row-major [rows, D] -> DSS_PLANAR64 [D/64, rows, 64]"""
+    rows, d = t2d.shape
+    return t2d.reshape(rows, d // 64, 64).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("res_dtype", [torch.float16, torch.bfloat16])
+def test_layernorm_planar_residual_is_bit_identical_to_row_major(res_dtype):
+    rows, d = 1803, 384
+    g = torch.Generator().manual_seed(9)
+    x, r = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g).to(res_dtype)
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    xa, xb = x.to(DEV), x.to(DEV)
+    a = hip.layernorm(xa, gamma, beta, 1e-6, torch.float16, residual=r.to(DEV))
+    b = hip.layernorm(xb, gamma, beta, 1e-6, torch.float16, residual=_to_planar(r).to(DEV), residual_planar=True)
+    assert torch.equal(a, b) and torch.equal(xa, xb)
+    assert torch.equal(xa.cpu(), x + r.float())
+
+
+# ----------------------------------------------------------------------------- Linear with K = 384 (qkv / proj / fc1)
+@pytest.mark.parametrize("m,n", [(901, 1152), (512, 384), (1, 64), (77, 1536), (1025, 128), (2 * 3601 + 5, 384)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("planar", [False, True])
+def test_linear_k384_matches_fp32_reference(m, n, dtype, gelu, planar):
+    """The plain PyTorch fp32 op of the same definition (F.linear, then DINO's exact erf GELU) on the same rounded
+    operands; tolerance = the output rounding of the half dtype (fp32 accumulation inside).  Shapes cover ragged
+    M (not a multiple of the 512-row workgroup or the 64-row wave tile) and every N the ViTs use."""
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, 384, generator=g).to(dtype)
+    w = (torch.randn(n, 384, generator=g) * 0.05).to(dtype)
+    b = (torch.randn(n, generator=g) * 0.2).to(dtype)
+    ref = F.linear(x.float(), w.float(), b.float())
+    if gelu:
+        ref = F.gelu(ref)
+    guard = 4                                                   # rows after the output must stay untouched
+    out = hip.linear_k384(x.to(DEV), w.to(DEV), b.to(DEV), gelu=gelu, planar=planar)
+    out = (hip.planar_to_rows(out) if planar else out).float().cpu()
+    assert out.shape == (m, n) and guard
+    tol = (1.0e-3 if dtype == torch.float16 else 8e-3) * max(1.0, ref.abs().max().item())
+    assert (out - ref).abs().max().item() <= tol
+    if gelu:  # the negative tail is where an erf approximation would show: absolute error well under f16 spacing
+        neg = ref < -0.05
+        if neg.any():
+            assert (out - ref)[neg].abs().max().item() <= (5e-4 if dtype == torch.float16 else 4e-3)
+
+
+def test_linear_k384_does_not_write_past_the_output():
+    m, n = 515, 128
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(m, 384, generator=g).half().to(DEV)
+    w = (torch.randn(n, 384, generator=g) * 0.05).half().to(DEV)
+    b = torch.zeros(n).half().to(DEV)
+    for planar in (False, True):
+        big = torch.full((m * n + 4096,), 7.0, dtype=torch.float16, device=DEV)
+        lib = hip.load_library()
+        rc = lib.dss_linear_k384(x.data_ptr(), w.data_ptr(), b.data_ptr(), big.data_ptr(), m, n, 0,
+                                 hip.PLANAR64 if planar else hip.ROW_MAJOR, hip.dtype_code(torch.float16),
+                                 torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.all(big[m * n:] == 7.0)
+        assert not torch.any(big[: m * n] == 7.0)
+
+
+def test_linear_k384_rejects_bad_shapes():
+    x = torch.zeros(8, 384, dtype=torch.float16, device=DEV)
+    w = torch.zeros(96, 384, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="dss_linear_k384"):
+        hip.linear_k384(x, w, torch.zeros(96, dtype=torch.float16, device=DEV))
+
+
 # ----------------------------------------------------------------------------- attention
 def _attention_ref(qkv, heads, scale):
     b, t, _ = qkv.shape
@@ -98,6 +170,16 @@ def test_attention_matches_fp64_reference(b, t, heads, dtype, impl, monkeypatch)
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     assert err <= tol * max(1.0, ref.abs().max().item()), err
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("b,t,heads", [(2, 901, 6), (1, 197, 6), (3, 130, 12), (1, 65, 1)])
+def test_attention_planar_qkv_is_bit_identical_to_interleaved(b, t, heads):
+    g = torch.Generator().manual_seed(b + t)
+    qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 1.5).half()
+    a = hip.attention(qkv.to(DEV), heads, 0.125)
+    planar = _to_planar(qkv.reshape(b * t, -1)).to(DEV)          # [3*heads, B*T, 64]
+    p = hip.attention(planar, heads, 0.125, planar_bt=(b, t))
+    assert torch.equal(a, p)
 
 
 @pytest.mark.parametrize("impl", ["2", "1"])
