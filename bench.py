@@ -5,8 +5,9 @@ and a CPU baseline (the oracle, i.e. the reference's numpy/scipy/torch-CPU path)
     python bench.py [--gpus N --steps K --warmup W]          # N=1 directly; N>1 under torch.distributed.run
 
 Workload (BASELINE.json configs[1]): dino_vits16, 480x480 synthetic VOC-shaped images, K=5.
-One STEP = one batch of ``--batch`` images (default 1024) already resident in HBM as uint8 HWC:
-transform+crop+im2col -> ViT (HIP LayerNorm/attention, hipBLASLt GEMMs) -> K features -> normalise ->
+One STEP = one batch of ``--batch`` images (default 4 ViT forwards of 290 = 1160 at the headline config) already
+resident in HBM as uint8 HWC:
+transform+crop+im2col -> ViT (HIP LayerNorm/attention/K-resident Linear kernels, hipBLASLt for the other GEMMs) -> K features -> normalise ->
 affinity -> Lanczos eigenpairs -> [K, N] eigenvectors.  One ``B=1`` result per image, like the reference.
 Every rank streams its own results to pinned host memory asynchronously, step by step (that is where the CLI
 writes the per-image .pth files from).  Multi-GPU: every rank runs the same number of steps on its own images
@@ -42,8 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
-    ap.add_argument("--vit-batch", type=int, default=256, help="images per ViT forward")
+    ap.add_argument("--batch", type=int, default=0, help="images per step per GPU (0 = 4 ViT forwards)")
+    ap.add_argument("--vit-batch", type=int, default=0,
+                    help="images per ViT forward (0 = near 256, sized so the token matrix fills whole waves of "
+                         "workgroups: vit.wave_filling_batch; 290 for dino_vits16 at 480x480)")
     ap.add_argument("--model", default="dino_vits16")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--K", type=int, default=5)
@@ -108,6 +111,12 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + 2N(N+1) out
                 byts = (4.0 * m["n"] * m["d"] + 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif name == "linear_k384":
+            # both pipes matter: 2*M*N*384 flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input)
+            flops = np.mean([2.0 * m["m"] * m["n"] * 384 for m in metas])
+            outb = np.mean([2.0 * m["m"] * m["n"] for m in metas])
+            entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s",
+                         output_GBs=round(outb / (avg * 1e-3) / 1e9, 1))
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
@@ -176,6 +185,11 @@ def main():
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu)
     n_patches = (a.size // patch) ** 2
+    if a.vit_batch <= 0:
+        from dss_amd.vit import wave_filling_batch
+        a.vit_batch = wave_filling_batch(n_patches + 1) if model.embed_dim == 384 else 256
+    if a.batch <= 0:
+        a.batch = 4 * a.vit_batch
 
     # synthetic images, resident in HBM before the timed region (rank r owns global indices r, r+world, ...)
     n_distinct = min(a.distinct, a.batch * (a.steps + a.warmup))

@@ -32,35 +32,54 @@ static constexpr int LWAVES = 8;          // two ping-pong groups of 4
 static constexpr int LTHREADS = 64 * LWAVES;
 static constexpr int LBM = 64 * LWAVES;   // token rows per workgroup (64 per wave)
 static constexpr int LMAXN = 2048;        // bias staged in LDS (fp32)
+static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
 static constexpr int LCHUNK_BYTES = LBN * LK * 2;   // 24576
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// GELU(x) = x * 0.5 * (1 + erf(x / sqrt 2)) for two values.  erf by A&S 7.1.28 on z = |x| / sqrt 2:
-// erf z = 1 - q^-16, q = 1 + a1 z + ... + a6 z^6.  Written as hx + |hx| * (1 - q^-16), hx = x / 2: the negative
-// branch cancels to -|hx| q^-16 with absolute error ~6e-8 |x|, far below the f16 rounding of the output.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  f32x2 ax;
-  ax[0] = fabsf(x[0]);
-  ax[1] = fabsf(x[1]);
-  const f32x2 z = ax * 0.70710678118654752f;
-  f32x2 q = z * 0.0000430638f + 0.0002765672f;
-  q = q * z + 0.0001520143f;
-  q = q * z + 0.0092705272f;
-  q = q * z + 0.0422820123f;
-  q = q * z + 0.0705230784f;
-  q = q * z + 1.0f;
-  q = q * q;
-  q = q * q;
-  q = q * q;
-  q = q * q;                                               // q^16 (inf for |x| > ~30: 1/inf = 0, erf = 1)
-  f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(q[0]);
-  r[1] = __builtin_amdgcn_rcpf(q[1]);
-  const f32x2 hx = x * 0.5f;
-  const f32x2 ahx = ax * 0.5f;
-  return hx + ahx * (1.0f - r);
+// GELU(x) = x * 0.5 * (1 + erf(x / sqrt 2)), NP float2 at a time, in place.  erf by A&S 7.1.28 on
+// z = |x| / sqrt 2: erf z = 1 - q^-16, q = 1 + a1 z + ... + a6 z^6 (|error| <= 3e-7: one v_rcp, no v_exp).  Evaluated
+// as x/2 + (|x|/2) (1 - q^-16): the negative branch cancels to -(|x|/2) q^-16 with absolute error ~6e-8 |x|, far
+// below the f16 rounding of the output.  The chain of one value is 17 dependent VALU ops (the probe measures
+// latency-, not issue-bound execution), so NP pairs are advanced in lockstep: every step below is NP independent
+// v_pk_* instructions.
+template <int NP>
+__device__ __forceinline__ void gelu_erf2xn(f32x2* x) {
+  f32x2 z[NP], q[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    f32x2 ax;
+    ax[0] = fabsf(x[j][0]);
+    ax[1] = fabsf(x[j][1]);
+    z[j] = ax * 0.70710678118654752f;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = z[j] * 0.0000430638f + 0.0002765672f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = q[j] * z[j] + 0.0001520143f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = q[j] * z[j] + 0.0092705272f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = q[j] * z[j] + 0.0422820123f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = q[j] * z[j] + 0.0705230784f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = q[j] * z[j] + 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                            // q^16 (inf for |x| > ~30: 1/inf = 0, erf = 1)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) q[j] = q[j] * q[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    q[j][0] = __builtin_amdgcn_rcpf(q[j][0]);
+    q[j][1] = __builtin_amdgcn_rcpf(q[j][1]);
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = (1.0f - q[j]) * (z[j] * 0.70710678118654752f);   // (|x|/2) erf
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] = x[j] * 0.5f + q[j];
 }
 
 template <class T, bool GELU>
@@ -78,6 +97,7 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
   const bool group_x = wave < LWAVES / 2;
   const int mrem = M - blockIdx.x * LBM;                   // rows of this workgroup that exist (> 0)
   const int rloc = wave * 64;                              // this wave's first row inside the workgroup
+  const bool block_full = mrem >= LBM;
 
   // ---- this lane's two token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ---------------------------
   V8 a0[LKS], a1[LKS];
@@ -86,6 +106,8 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
     const long r1 = (long)blockIdx.x * LBM + min(rloc + 32 + li, mrem - 1);
 #pragma unroll
     for (int s = 0; s < LKS; ++s) {
+      // plain loads: a 128-byte line of A is touched by 8 of these instructions (4 k-steps x 2 halves); with
+      // non-temporal loads it is re-fetched from HBM each time (measured: qkv 255 -> 291 us)
       a0[s] = *reinterpret_cast<const V8*>(A + r0 * LK + 16 * s + 8 * hh);
       a1[s] = *reinterpret_cast<const V8*>(A + r1 * LK + 16 * s + 8 * hh);
     }
@@ -111,6 +133,22 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
     }
   };
   auto wait_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  // phase barrier WITHOUT the release fence of __syncthreads(): that fence makes the compiler drain vmcnt to 0 (the
+  // tile stores!) in front of every barrier.  Nothing crosses waves through memory inside the loop except the W
+  // chunks, whose arrival is awaited explicitly (wait_dma) by the issuing waves.
+  auto phase_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // vmcnt retires in issue order (gfx9: loads, LDS-DMA and stores share it): with the 8 tile stores of an odd chunk
+  // issued AFTER the DMA of the next W chunk, vmcnt(8) waits for the DMA (and everything older) but not for those
+  // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
+  // Ragged workgroups predicate their stores (unknown count): they wait for everything.
+  auto wait_dma = [&](int c_stored) {
+    if (block_full && (c_stored & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
 
   for (int i = tid; i < N; i += LTHREADS) Bs[i] = to_f32<T>(bias[i]);
 
@@ -128,23 +166,21 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
   const size_t gstride = planar ? (size_t)M * 128 : 128;
   unsigned char* cblk = reinterpret_cast<unsigned char*>(C) + (size_t)blockIdx.x * LBM * ldc;
   const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
-  const bool block_full = mrem >= LBM;
 
   f32x16 acc0, acc1;
 
-  // ---- MFMA phase of chunk c: acc = bias + W_chunk . A^T --------------------------------------------------------
-  auto mfma_phase = [&](int c) {
-    const float* bch = &Bs[c * LBN + 4 * hh];              // register group g = output columns 8g + 4hh .. +3
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bch + 8 * g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { acc0[4 * g + i] = bv[i]; acc1[4 * g + i] = bv[i]; }
-    }
+  // ---- MFMA phase of chunk c: acc = W_chunk . A^T + bias.  The bias rides on a 25th k-step issued LAST: its W
+  //      fragment is (bias[col], 0, ..) and its A fragment (1, 0, ..), both only in the hh = 0 half (k = 0), so the
+  //      phase starts with a zero accumulator and no LDS round trip in front of the first MFMA.
+  auto mfma_phase = [&](int c, int stage_next) {
     const unsigned char* wb = &Ws[c & 1][16 * lane];
     V8 f[3];
     f[0] = *reinterpret_cast<const V8*>(wb);
     f[1] = *reinterpret_cast<const V8*>(wb + 1024);
+    const float bcol = Bs[c * LBN + li];
+    if (stage_next >= 0) stage(stage_next);                // DMA issue behind the first fragment reads
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < LKS; ++s) {
@@ -152,6 +188,14 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
       acc0 = mfma32x32x16(f[s % 3], a0[s], acc0);          // D[col][row] += W[col][k] * A[row][k]
       acc1 = mfma32x32x16(f[s % 3], a1[s], acc1);
     }
+    V8 fb, a_one;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fb[e] = from_f32<T>((e == 0 && hh == 0) ? bcol : 0.0f);
+      a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
+    }
+    acc0 = mfma32x32x16(fb, a_one, acc0);
+    acc1 = mfma32x32x16(fb, a_one, acc1);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -160,15 +204,12 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
     const unsigned half = 64u * (c & 1);                   // which half of the 128-byte row
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      f32x2 v[4] = {{acc0[4 * g], acc0[4 * g + 1]}, {acc0[4 * g + 2], acc0[4 * g + 3]},
+                    {acc1[4 * g], acc1[4 * g + 1]}, {acc1[4 * g + 2], acc1[4 * g + 3]}};
+      if (GELU) { gelu_erf2xn<LGELU_ILP>(v); if (LGELU_ILP < 4) gelu_erf2xn<LGELU_ILP>(v + 2); }
       V4 o0, o1;
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        f32x2 v0 = {acc0[4 * g + i], acc0[4 * g + i + 1]};
-        f32x2 v1 = {acc1[4 * g + i], acc1[4 * g + i + 1]};
-        if (GELU) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
-        o0[i] = from_f32<T>(v0[0]); o0[i + 1] = from_f32<T>(v0[1]);
-        o1[i] = from_f32<T>(v1[0]); o1[i + 1] = from_f32<T>(v1[1]);
-      }
+      o0[0] = from_f32<T>(v[0][0]); o0[1] = from_f32<T>(v[0][1]); o0[2] = from_f32<T>(v[1][0]); o0[3] = from_f32<T>(v[1][1]);
+      o1[0] = from_f32<T>(v[2][0]); o1[1] = from_f32<T>(v[2][1]); o1[2] = from_f32<T>(v[3][0]); o1[3] = from_f32<T>(v[3][1]);
       unsigned char* wp = stg_w + ((half + 16 * g) ^ stg_x);
       *reinterpret_cast<V4*>(wp) = o0;
       *reinterpret_cast<V4*>(wp + 4096) = o1;
@@ -179,41 +220,40 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
     if (block_full) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff) =
-            *reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i);
+        __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
+                                    reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (rloc + rq + 8 * i < mrem)
-          *reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff) =
-              *reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i);
+          __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
+                                      reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
     }
   };
 
   // ---- ping-pong over the chunks.  Phase 2c: X multiplies chunk c, Y finishes chunk c-1; phase 2c+1: swapped.
-  //      Chunk c+1 is DMA'd into the other buffer during phase 2c (last read in phase 2c-1) and awaited before the
-  //      barrier that ends phase 2c+1; by then the epilogue stores issued a phase earlier have drained too.
+  //      Chunk c+1 is DMA'd into the other buffer during phase 2c (last read in phase 2c-1) and awaited (wait_dma)
+  //      before the barrier that ends phase 2c+1.
   const int nchunks = N / LBN;
   stage(0);
   wait_vm();
   __syncthreads();
   if (group_x) {
     for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) stage(c + 1);
-      mfma_phase(c);
-      __syncthreads();
-      wait_vm();
+      mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
+      phase_barrier();
       epilogue(c);
-      __syncthreads();
+      wait_dma(c);
+      phase_barrier();
     }
   } else {
     for (int c = 0; c < nchunks; ++c) {
       if (c + 1 < nchunks) stage(c + 1);
       if (c > 0) epilogue(c - 1);
-      __syncthreads();
-      mfma_phase(c);
-      wait_vm();
-      __syncthreads();
+      phase_barrier();
+      mfma_phase(c, -1);
+      wait_dma(c > 0 ? c - 1 : 0);
+      phase_barrier();
     }
     epilogue(nchunks - 1);
   }

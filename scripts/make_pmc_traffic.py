@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""profiles/rNN_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/gpu_check.sh pmc.
+
+    python scripts/make_pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_FETCH_SIZE.csv \
+        gpurun_out/pmc_WRITE_SIZE/pmc_WRITE_SIZE.csv gpurun_out/pmc_FETCH_SIZE/bench.json profiles/r01_pmc_traffic.json
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE is doubled per
+MI355X_MICROARCH.md section HBM (gfx950 counts 128-byte requests as 64 B; checked in the same run on a plain
+elementwise torch kernel whose traffic is known)."""
+import csv
+import json
+import sys
+
+KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
+    "linear_k384": "linear_k384_kernel",
+    "attention": "attn_fwd2_kernel",
+    "laplacian_eigs": "laplacian_eigs_kernel",
+    "affinity": "gram_split_kernel",
+    "layernorm": "layernorm_kernel",
+    "normalize_rows_split": "normalize_rows_split_kernel",
+    "torch_gelu (FETCH_SIZE calibration)": "GeluCUDAKernelImpl",
+    "torch_elementwise (FETCH_SIZE calibration)": "vectorized_elementwise_kernel",
+}
+
+
+def load(path):
+    rows = {}
+    with open(path) as f:
+        for r in csv.DictReader(l for l in f if not l.startswith("#")):
+            rows[r["kernel"]] = (int(r["dispatches"]), float(r["avg_value"]), float(r["avg_us"]))
+    return rows
+
+
+def main():
+    fetch, write, bench_json, out = sys.argv[1:5]
+    fr, wr = load(fetch), load(write)
+    cfg = json.loads(open(bench_json).read().strip().splitlines()[-1])["config"]
+    kernels = {}
+    for key, sub in KEYS.items():
+        names = [n for n in fr if sub in n and n in wr]
+        if not names:
+            continue
+        # several template instantiations (e.g. GELU / no GELU) share a key: dispatch-weighted average
+        nd = sum(fr[n][0] for n in names)
+        f = sum(fr[n][0] * fr[n][1] for n in names) / nd
+        w = sum(wr[n][0] * wr[n][1] for n in names) / sum(wr[n][0] for n in names)
+        us = sum(fr[n][0] * fr[n][2] for n in names) / nd
+        kernels[key] = {"rocprof_name": names[0][:120], "instantiations": len(names), "dispatches": nd,
+                        "fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1),
+                        "hbm_bytes_per_launch": round((2 * f + w) * 1024, 1), "avg_us_under_pmc": round(us, 2)}
+    doc = {"_comment": __doc__.split("\n\n")[-1].replace("\n", " "),
+           "config": {"model": cfg["workload"].split()[0], "size": int(cfg["workload"].split()[1].split("x")[0]),
+                      "K": int(cfg["workload"].split("K=")[1].split(",")[0]), "batch": cfg["images_per_step"],
+                      "vit_batch": cfg["vit_batch"]},
+           "kernels": kernels}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc["config"]), list(kernels))
+
+
+if __name__ == "__main__":
+    main()
