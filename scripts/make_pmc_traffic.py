@@ -19,7 +19,6 @@ KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
     "layernorm": "layernorm_kernel",
     "normalize_rows_split": "normalize_rows_split_kernel",
     "torch_gelu (FETCH_SIZE calibration)": "GeluCUDAKernelImpl",
-    "torch_elementwise (FETCH_SIZE calibration)": "vectorized_elementwise_kernel",
 }
 
 
