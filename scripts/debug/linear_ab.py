@@ -8,10 +8,6 @@ setup_gemm_tuning()
 torch.manual_seed(0)
 M = 256 * 901  # multiple of the 256-row workgroup tile
 x = (torch.randn(M, 384, device='cuda') * 1.0).half()
-if os.environ.get("PROF"):
-    w = (torch.randn(1152, 384, device='cuda') * 0.05).half(); b = (torch.randn(1152, device='cuda') * 0.1).half()
-    for _ in range(5): hip.linear_k384(x, w, b, False)
-    torch.cuda.synchronize(); sys.exit(0)
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -145,3 +145,24 @@ def test_single_region_segmentation_matches_reference_golden(tmp_path, golden_di
     extract.extract_single_region_segmentations(str(tmp_path / "f"), str(tmp_path / "e"), str(tmp_path / "o"))
     png = np.array(Image.open(tmp_path / "o" / "seg_x.png"))
     assert png.dtype == g["png"].dtype and np.array_equal(png, g["png"])
+
+
+def test_wave_filling_batch_picks_whole_waves_of_workgroups():
+    """vit.wave_filling_batch: images per ViT forward such that ceil(b * tokens / 512) workgroups of the K-resident
+    Linear kernel fill whole waves of the CUs (pure arithmetic; no GPU)."""
+    import math
+
+    from dss_amd.vit import wave_filling_batch
+
+    b = wave_filling_batch(901, target=256, compute_units=256)          # 480x480 / patch 16 + CLS
+    assert b == 290
+    tiles = math.ceil(b * 901 / 512)
+    assert tiles <= 512 and tiles / 512 > 0.99                           # 511 workgroups = 1.996 waves
+    for tokens in (197, 401, 901, 3601):
+        for cus in (64, 256, 304):
+            b = wave_filling_batch(tokens, target=256, compute_units=cus)
+            assert 0.85 * 256 - 1 <= b <= 1.25 * 256 + 1
+            t = b * tokens / 512
+            eff = t / (math.ceil(math.ceil(t) / cus) * cus)
+            base = (256 * tokens / 512) / (math.ceil(math.ceil(256 * tokens / 512) / cus) * cus)
+            assert eff >= base - 1e-9                                    # never worse than the plain target
