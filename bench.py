@@ -114,9 +114,9 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + 2N(N+1) out
                 byts = (4.0 * m["n"] * m["d"] + 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        elif name == "linear_k384":
-            # both pipes matter: 2*M*N*384 flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input)
-            flops = np.mean([2.0 * m["m"] * m["n"] * 384 for m in metas])
+        elif name == "linear_kres":
+            # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input)
+            flops = np.mean([2.0 * m["m"] * m["n"] * m["k"] for m in metas])
             outb = np.mean([2.0 * m["m"] * m["n"] for m in metas])
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s",
                          output_GBs=round(outb / (avg * 1e-3) / 1e9, 1))
@@ -190,7 +190,9 @@ def main():
     n_patches = (a.size // patch) ** 2
     if a.vit_batch <= 0:
         from dss_amd.vit import wave_filling_batch
-        a.vit_batch = wave_filling_batch(n_patches + 1) if model.embed_dim == 384 else 256
+        rows = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
+        target = min(256, max(8, round(256 * 901 / (n_patches + 1))))   # at most the token count of the headline config
+        a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
     if a.batch <= 0:
         # the eigensolver runs one 1024-thread workgroup per image, one per CU: pick the number of ViT forwards per
         # step (4..8) whose image count best fills whole waves of CUs (290 x 7 = 2030 = 7.93 x 256)

@@ -1,5 +1,6 @@
-// linear384.hip - Linear layers of the D = 384 DINO ViTs (vits16 / vits8) whose reduction dimension is the
-// embedding width: qkv (384 -> 1152), attn.proj (384 -> 384), mlp.fc1 (384 -> 1536, + exact GELU).
+// linear384.hip - Linear layers of the DINO ViTs whose reduction dimension is the embedding width:
+// qkv (D -> 3D), attn.proj (D -> D), mlp.fc1 (D -> 4D, + exact GELU), for D = 384 (vits16 / vits8: the kernel was
+// designed on these shapes, hence the file name) and D = 768 (vitb16 / vitb8).
 //
 // Replaces torch.nn.Linear / F.gelu inside DINO's Block (reached from extract/extract.py:94).
 // These GEMMs write 1.5 - 4x more bytes than they read (M = 230k token rows, K = 384): a library GEMM spends them in
@@ -18,6 +19,9 @@
 //   * the product is D[col][row] = W_chunk . A^T, so a lane owns token rows; the wave transposes its 64 x 64 output
 //     tile (two chunks) through a private 8 KB LDS patch and stores FULL 128-byte lines, 8 rows per instruction.
 //     Measured for qkv: 8-byte pieces 404 us, 64-byte half lines 310 us, full lines 268 us (same MFMA loop).
+//   * D = 768 is the same kernel with ONE row tile per wave (32 rows x 768 = the same 192 VGPRs): every W fragment
+//     then feeds one MFMA instead of two (twice the LDS reads per FLOP), the two accumulator chains are the even
+//     and odd k-steps, and a chunk's epilogue is half as long relative to its MFMA phase.
 //   * bias is the accumulators' initial value; GELU is exact-erf by Abramowitz-Stegun 7.1.28
 //     (erf z = 1 - (1 + a1 z + .. + a6 z^6)^-16, |error| <= 3e-7: one v_rcp, no v_exp), written on float2 so the
 //     polynomial runs on v_pk_fma_f32 / v_pk_mul_f32.
@@ -25,15 +29,22 @@
 
 namespace dss {
 
-static constexpr int LK = 384;            // reduction dimension (embedding width of vits*)
-static constexpr int LKS = LK / 16;       // 24 MFMA k-steps
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
 static constexpr int LWAVES = 8;          // two ping-pong groups of 4
 static constexpr int LTHREADS = 64 * LWAVES;
-static constexpr int LBM = 64 * LWAVES;   // token rows per workgroup (64 per wave)
-static constexpr int LMAXN = 2048;        // bias staged in LDS (fp32)
 static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
-static constexpr int LCHUNK_BYTES = LBN * LK * 2;   // 24576
+
+// KS = K / 16 MFMA k-steps held per token row; RT = 32-row tiles per wave.  KS * RT = 48 fragments = 192 VGPRs.
+template <int KS, int RT> struct LinCfg {
+  static_assert(KS * RT == 48 && KS % LWAVES == 0, "the A operand of a wave is 48 fragments");
+  static constexpr int K = 16 * KS;
+  static constexpr int ROWS_WAVE = 32 * RT;
+  static constexpr int ROWS = ROWS_WAVE * LWAVES;           // token rows per workgroup
+  static constexpr int CHUNK_BYTES = LBN * K * 2;           // 24 KB (K = 384) / 48 KB (K = 768), double buffered
+  static constexpr int PATCH_BYTES = ROWS_WAVE * 128;       // transpose patch of one wave: two chunks of f16
+  static constexpr int MAXN = KS == 24 ? 2048 : 3072;       // bias table in LDS (fp32)
+  static constexpr int NSTORE = 4 * RT;                     // 16-byte stores per lane per finished 64-column group
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -82,43 +93,43 @@ __device__ __forceinline__ void gelu_erf2xn(f32x2* x) {
   for (int j = 0; j < NP; ++j) x[j] = x[j] * 0.5f + q[j];
 }
 
-template <class T, bool GELU>
-__global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __restrict__ A, const T* __restrict__ W,
+template <class T, bool GELU, int KS, int RT>
+__global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                                  const T* __restrict__ bias, T* __restrict__ C,
                                                                  int M, int N, int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
-  __shared__ __attribute__((aligned(256))) unsigned char Ws[2][LCHUNK_BYTES];
-  __shared__ __attribute__((aligned(256))) unsigned char Stg[LWAVES][8192];
-  __shared__ __attribute__((aligned(16))) float Bs[LMAXN];
+  typedef LinCfg<KS, RT> Cfg;
+  constexpr int LK = Cfg::K, LKS = KS, LBM = Cfg::ROWS;
+  __shared__ __attribute__((aligned(256))) unsigned char Ws[2][Cfg::CHUNK_BYTES];
+  __shared__ __attribute__((aligned(256))) unsigned char Stg[LWAVES][Cfg::PATCH_BYTES];
+  __shared__ __attribute__((aligned(16))) float Bs[Cfg::MAXN];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const bool group_x = wave < LWAVES / 2;
   const int mrem = M - blockIdx.x * LBM;                   // rows of this workgroup that exist (> 0)
-  const int rloc = wave * 64;                              // this wave's first row inside the workgroup
+  const int rloc = wave * Cfg::ROWS_WAVE;                  // this wave's first row inside the workgroup
   const bool block_full = mrem >= LBM;
 
-  // ---- this lane's two token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ---------------------------
-  V8 a0[LKS], a1[LKS];
-  {
-    const long r0 = (long)blockIdx.x * LBM + min(rloc + li, mrem - 1);
-    const long r1 = (long)blockIdx.x * LBM + min(rloc + 32 + li, mrem - 1);
+  // ---- this lane's RT token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ----------------------------
+  V8 a[RT][LKS];
 #pragma unroll
-    for (int s = 0; s < LKS; ++s) {
+  for (int t = 0; t < RT; ++t) {
+    const long r = (long)blockIdx.x * LBM + min(rloc + 32 * t + li, mrem - 1);
+#pragma unroll
+    for (int s = 0; s < LKS; ++s)
       // plain loads: a 128-byte line of A is touched by 8 of these instructions (4 k-steps x 2 halves); with
       // non-temporal loads it is re-fetched from HBM each time (measured: qkv 255 -> 291 us)
-      a0[s] = *reinterpret_cast<const V8*>(A + r0 * LK + 16 * s + 8 * hh);
-      a1[s] = *reinterpret_cast<const V8*>(A + r1 * LK + 16 * s + 8 * hh);
-    }
+      a[t][s] = *reinterpret_cast<const V8*>(A + r * LK + 16 * s + 8 * hh);
   }
 
-  // ---- W chunk staging by LDS-DMA: instruction j of wave w stages k-step s = 3 w + j (64 lanes x 16 B = 1 KB):
+  // ---- W chunk staging by LDS-DMA: instruction j of wave w stages k-step s = NST w + j (64 lanes x 16 B = 1 KB):
   //      lane (li, hh) fetches W[chunk col li][16 s + 8 hh .. + 8] and the hardware writes it at base + 16 * lane.
-  constexpr int NST = LKS / LWAVES;                        // 3
+  constexpr int NST = LKS / LWAVES;                        // 3 (K = 384) / 6 (K = 768)
   const unsigned gsrc0 = (unsigned)(li * (LK * 2) + 16 * hh + 32 * (wave * NST));
   auto stage = [&](int c) {
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(W) + (size_t)c * LCHUNK_BYTES;  // uniform
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(W) + (size_t)c * Cfg::CHUNK_BYTES;  // uniform
     const unsigned dst0 = (unsigned)(size_t)(lds_ptr_t)(&Ws[c & 1][wave * NST * 1024]);
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
@@ -146,13 +157,17 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
   // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
   // Ragged workgroups predicate their stores (unknown count): they wait for everything.
   auto wait_dma = [&](int c_stored) {
-    if (block_full && (c_stored & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (block_full && (c_stored & 1)) {
+      if (Cfg::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   };
 
   for (int i = tid; i < N; i += LTHREADS) Bs[i] = to_f32<T>(bias[i]);
 
-  // ---- output: 8 KB transpose patch per wave (64 rows x 128 B; 16-byte slot p of row r lives at slot
+  // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
   //      p ^ ((r >> 1) & 7): writes 2-way, reads conflict-free) + (uniform base, 32-bit lane offset) addressing
   unsigned char* stg = &Stg[wave][0];
   unsigned char* stg_w = stg + li * 128 + 8 * hh;          // writer: row li (+32 for the second row tile)
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
   unsigned char* cblk = reinterpret_cast<unsigned char*>(C) + (size_t)blockIdx.x * LBM * ldc;
   const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
 
-  f32x16 acc0, acc1;
+  f32x16 acc0, acc1;   // RT = 2: row tiles 0 / 1.  RT = 1: even / odd k-steps of the one row tile (two MFMA chains)
 
   // ---- MFMA phase of chunk c: acc = W_chunk . A^T + bias.  The bias rides on a 25th k-step issued LAST: its W
   //      fragment is (bias[col], 0, ..) and its A fragment (1, 0, ..), both only in the hh = 0 half (k = 0), so the
@@ -185,8 +200,14 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
 #pragma unroll
     for (int s = 0; s < LKS; ++s) {
       if (s + 2 < LKS) f[(s + 2) % 3] = *reinterpret_cast<const V8*>(wb + 1024 * (s + 2));
-      acc0 = mfma32x32x16(f[s % 3], a0[s], acc0);          // D[col][row] += W[col][k] * A[row][k]
-      acc1 = mfma32x32x16(f[s % 3], a1[s], acc1);
+      if (RT == 2) {
+        acc0 = mfma32x32x16(f[s % 3], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
+        acc1 = mfma32x32x16(f[s % 3], a[RT - 1][s], acc1);
+      } else if (s & 1) {
+        acc1 = mfma32x32x16(f[s % 3], a[0][s], acc1);
+      } else {
+        acc0 = mfma32x32x16(f[s % 3], a[0][s], acc0);
+      }
     }
     V8 fb, a_one;
 #pragma unroll
@@ -195,36 +216,45 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
       a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
     }
     acc0 = mfma32x32x16(fb, a_one, acc0);
-    acc1 = mfma32x32x16(fb, a_one, acc1);
+    if (RT == 2) acc1 = mfma32x32x16(fb, a_one, acc1);
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 64 rows x 128 B ---
+  // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 32 RT rows x 128 B
   auto epilogue = [&](int c) {
     const unsigned half = 64u * (c & 1);                   // which half of the 128-byte row
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x2 v[4] = {{acc0[4 * g], acc0[4 * g + 1]}, {acc0[4 * g + 2], acc0[4 * g + 3]},
-                    {acc1[4 * g], acc1[4 * g + 1]}, {acc1[4 * g + 2], acc1[4 * g + 3]}};
-      if (GELU) { gelu_erf2xn<LGELU_ILP>(v); if (LGELU_ILP < 4) gelu_erf2xn<LGELU_ILP>(v + 2); }
-      V4 o0, o1;
-      o0[0] = from_f32<T>(v[0][0]); o0[1] = from_f32<T>(v[0][1]); o0[2] = from_f32<T>(v[1][0]); o0[3] = from_f32<T>(v[1][1]);
-      o1[0] = from_f32<T>(v[2][0]); o1[1] = from_f32<T>(v[2][1]); o1[2] = from_f32<T>(v[3][0]); o1[3] = from_f32<T>(v[3][1]);
       unsigned char* wp = stg_w + ((half + 16 * g) ^ stg_x);
-      *reinterpret_cast<V4*>(wp) = o0;
-      *reinterpret_cast<V4*>(wp + 4096) = o1;
+      if (RT == 2) {
+        f32x2 v[4] = {{acc0[4 * g], acc0[4 * g + 1]}, {acc0[4 * g + 2], acc0[4 * g + 3]},
+                      {acc1[4 * g], acc1[4 * g + 1]}, {acc1[4 * g + 2], acc1[4 * g + 3]}};
+        if (GELU) { gelu_erf2xn<LGELU_ILP>(v); if (LGELU_ILP < 4) gelu_erf2xn<LGELU_ILP>(v + 2); }
+        V4 o0, o1;
+        o0[0] = from_f32<T>(v[0][0]); o0[1] = from_f32<T>(v[0][1]); o0[2] = from_f32<T>(v[1][0]); o0[3] = from_f32<T>(v[1][1]);
+        o1[0] = from_f32<T>(v[2][0]); o1[1] = from_f32<T>(v[2][1]); o1[2] = from_f32<T>(v[3][0]); o1[3] = from_f32<T>(v[3][1]);
+        *reinterpret_cast<V4*>(wp) = o0;
+        *reinterpret_cast<V4*>(wp + 4096) = o1;
+      } else {
+        f32x2 v[2] = {{acc0[4 * g] + acc1[4 * g], acc0[4 * g + 1] + acc1[4 * g + 1]},
+                      {acc0[4 * g + 2] + acc1[4 * g + 2], acc0[4 * g + 3] + acc1[4 * g + 3]}};
+        if (GELU) gelu_erf2xn<2>(v);
+        V4 o0;
+        o0[0] = from_f32<T>(v[0][0]); o0[1] = from_f32<T>(v[0][1]); o0[2] = from_f32<T>(v[1][0]); o0[3] = from_f32<T>(v[1][1]);
+        *reinterpret_cast<V4*>(wp) = o0;
+      }
     }
     if (!(c & 1)) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS write -> read (other lanes' data)
     unsigned char* cw = cblk + (size_t)(c >> 1) * gstride;
     if (block_full) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < Cfg::NSTORE; ++i)
         __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
                                     reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < Cfg::NSTORE; ++i)
         if (rloc + rq + 8 * i < mrem)
           __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
                                       reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
@@ -259,35 +289,46 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_k384_kernel(const T* __res
   }
 }
 
-template <class T>
-static void launch_linear384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
-                             int planar, hipStream_t s) {
-  const int blocks = ceil_div(M, LBM);
+template <class T, int KS, int RT>
+static void launch_linear_kres(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
+                               int planar, hipStream_t s) {
+  const int blocks = ceil_div(M, LinCfg<KS, RT>::ROWS);
   if (gelu)
-    hipLaunchKernelGGL((linear_k384_kernel<T, true>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A, (const T*)W,
-                       (const T*)bias, (T*)C, M, N, planar);
+    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A,
+                       (const T*)W, (const T*)bias, (T*)C, M, N, planar);
   else
-    hipLaunchKernelGGL((linear_k384_kernel<T, false>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A, (const T*)W,
-                       (const T*)bias, (T*)C, M, N, planar);
+    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A,
+                       (const T*)W, (const T*)bias, (T*)C, M, N, planar);
+}
+
+template <int KS, int RT>
+static int linear_kres(const char* name, const void* A, const void* W, const void* bias, void* C, int M, int N,
+                       int gelu, int out_layout, int dtype, void* stream) {
+  typedef LinCfg<KS, RT> Cfg;
+  DSS_REQUIRE(A && W && bias && C, "%s: null pointer", name);
+  DSS_REQUIRE(M > 0 && N > 0 && N % (2 * LBN) == 0 && N <= Cfg::MAXN, "%s: need M > 0, N %% %d == 0, N <= %d (M=%d N=%d)",
+              name, 2 * LBN, Cfg::MAXN, M, N);
+  DSS_REQUIRE(out_layout == DSS_ROW_MAJOR || out_layout == DSS_PLANAR64,
+              "%s: out_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", name, out_layout);
+  hipStream_t s = (hipStream_t)stream;
+  const int planar = out_layout == DSS_PLANAR64;
+  switch (dtype) {
+    case DSS_F16: launch_linear_kres<f16, KS, RT>(A, W, bias, C, M, N, gelu, planar, s); break;
+    case DSS_BF16: launch_linear_kres<bf16, KS, RT>(A, W, bias, C, M, N, gelu, planar, s); break;
+    default: return fail(DSS_ERR_BAD_ARG, "%s: dtype must be DSS_F16 or DSS_BF16 (got %d)", name, dtype);
+  }
+  DSS_CHECK_LAUNCH(name);
+  return DSS_OK;
 }
 
 }  // namespace dss
 
 extern "C" int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
-  DSS_REQUIRE(A && W && bias && C, "dss_linear_k384: null pointer");
-  DSS_REQUIRE(M > 0 && N > 0 && N % (2 * dss::LBN) == 0 && N <= dss::LMAXN,
-              "dss_linear_k384: need M > 0, N %% %d == 0, N <= %d (M=%d N=%d)", 2 * dss::LBN, dss::LMAXN, M, N);
-  DSS_REQUIRE(out_layout == DSS_ROW_MAJOR || out_layout == DSS_PLANAR64,
-              "dss_linear_k384: out_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", out_layout);
-  DSS_REQUIRE((long)dss::LBM * N * 2 < (1L << 31), "dss_linear_k384: N too large");
-  hipStream_t s = (hipStream_t)stream;
-  const int planar = out_layout == DSS_PLANAR64;
-  switch (dtype) {
-    case DSS_F16: dss::launch_linear384<dss::f16>(A, W, bias, C, M, N, gelu, planar, s); break;
-    case DSS_BF16: dss::launch_linear384<dss::bf16>(A, W, bias, C, M, N, gelu, planar, s); break;
-    default: return dss::fail(DSS_ERR_BAD_ARG, "dss_linear_k384: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
-  }
-  DSS_CHECK_LAUNCH("linear_k384");
-  return DSS_OK;
+  return dss::linear_kres<24, 2>("dss_linear_k384", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
+}
+
+extern "C" int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
+                               int out_layout, int dtype, void* stream) {
+  return dss::linear_kres<48, 1>("dss_linear_k768", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
 }

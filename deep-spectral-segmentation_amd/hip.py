@@ -32,6 +32,7 @@ SYMBOLS = {
     "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
                                   c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -206,20 +207,34 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[t
     return out
 
 
-def linear_k384(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
+LINEAR_KRES_WIDTHS = {384: ("dss_linear_k384", 512), 768: ("dss_linear_k768", 256)}   # K -> (entry point, rows / workgroup)
+
+
+def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
                 planar: bool = False) -> torch.Tensor:
-    """``x [..., 384] @ weight[N, 384]^T + bias`` (optionally + exact erf-GELU) on the K-resident MFMA kernel.
-    Returns ``[..., N]``, or with ``planar`` the DSS_PLANAR64 form ``[N/64, rows, 64]``."""
-    assert x.shape[-1] == 384 and weight.shape[1] == 384 and x.dtype == weight.dtype == bias.dtype
+    """``x [..., K] @ weight[N, K]^T + bias`` (optionally + exact erf-GELU) on the K-resident MFMA kernel, K = 384 or
+    768.  Returns ``[..., N]``, or with ``planar`` the DSS_PLANAR64 form ``[N/64, rows, 64]``."""
+    k = x.shape[-1]
+    if k not in LINEAR_KRES_WIDTHS:
+        raise ValueError(f"linear_kres: reduction dimension must be one of {sorted(LINEAR_KRES_WIDTHS)} (got {k})")
+    assert weight.shape[1] == k and x.dtype == weight.dtype == bias.dtype
+    entry = LINEAR_KRES_WIDTHS[k][0]
     n = weight.shape[0]
-    m = x.numel() // 384
+    m = x.numel() // k
     shape = (n // 64, m, 64) if planar else (*x.shape[:-1], n)
     out = torch.empty(shape, dtype=x.dtype, device=x.device)
-    with _timed("linear_k384", m=m, n=n, gelu=gelu):
-        _check(load_library().dss_linear_k384(_dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(out, "out"),
+    with _timed("linear_kres", m=m, n=n, k=k, gelu=gelu):
+        _check(getattr(load_library(), entry)(_dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(out, "out"),
                                               m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
-                                              _stream()), "dss_linear_k384")
+                                              _stream()), entry)
     return out
+
+
+def linear_k384(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
+                planar: bool = False) -> torch.Tensor:
+    """``linear_kres`` for the K = 384 models (kept as the name the kernel was introduced under)."""
+    assert x.shape[-1] == 384
+    return linear_kres(x, weight, bias, gelu=gelu, planar=planar)
 
 
 # --------------------------------------------------------------------------------------- spectral stage

@@ -102,9 +102,10 @@ class DinoViT:
         # the TANH approximation (measured: 3.6e-7 from tanh-GELU, 4.7e-4 from erf-GELU).  It is NOT DINO's function:
         # opt-in only, never used for the reported numbers.
         self.gelu = gelu
-        # qkv / attn.proj of the D = 384 models on the K-resident kernel (dss_linear_k384) with planar outputs that
+        # qkv / attn.proj of the D = 384 / 768 models on the K-resident kernel (dss_linear_k384/_k768), planar outputs that
         # the attention and LayerNorm kernels read in place; DSS_LINEAR_K384=0 keeps the library GEMMs (A/B switch)
-        # (DSS_LINEAR_K384=1: qkv + proj only; 2, the default: also fc1 with the erf-GELU fused into its epilogue)
+        # (DSS_LINEAR_K384=1: qkv + proj only; 2, the default: also fc1 with the erf-GELU fused into its epilogue;
+        #  3: additionally fc1+GELU of the D = 768 models, measured slower there)
         self.linear_k384 = int(os.environ.get("DSS_LINEAR_K384", "2") or 0)
         d = self.embed_dim
         sd = state_dict
@@ -190,14 +191,20 @@ class DinoViT:
         ws = self._attn_workspace(b, t)
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
-        k384 = self.linear_k384 and d == 384   # K-resident GEMMs (planar outputs) for the D = 384 models
+        # K-resident Linear kernel: at D = 384 it beats the library GEMM on qkv, proj and fc1+GELU.  At D = 768 (one
+        # row tile per wave: every W fragment feeds one MFMA instead of two) the library wins on qkv / proj (916 vs
+        # 787 TF/s) and the fused fc1+GELU, 9 % faster in isolation, is 2.5 % slower end to end on dino_vitb8: there the
+        # kernel (dss_linear_k768) is only used when forced with DSS_LINEAR_K384=3.
+        k384 = self.linear_k384 and d == 384
+        kres_fc1 = self.gelu == "erf" and ((self.linear_k384 >= 2 and d == 384) or
+                                           (self.linear_k384 >= 3 and d in hip.LINEAR_KRES_WIDTHS))
         for i in range(wb):
             blk = self.blocks[i]
             hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             if k384:
-                qkv = hip.linear_k384(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)       # [3h, B*T, 64]
+                qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)       # [3h, B*T, 64]
                 o = hip.attention(qkv, heads, self.scale, workspace=ws, planar_bt=(b, t))
-                pending = hip.linear_k384(o, blk["proj_w"], blk["proj_b"], planar=True)    # [6, B*T, 64]
+                pending = hip.linear_kres(o, blk["proj_w"], blk["proj_b"], planar=True)    # [D/64, B*T, 64]
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
                                      residual_planar=True)
             else:
@@ -205,8 +212,8 @@ class DinoViT:
                 o = hip.attention(qkv, heads, self.scale, workspace=ws)
                 pending = F.linear(o, blk["proj_w"], blk["proj_b"])
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
-            if k384 and self.linear_k384 >= 2 and self.gelu == "erf":
-                f1 = hip.linear_k384(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)        # row-major: fc2 is a library GEMM
+            if kres_fc1:
+                f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)        # row-major: fc2 is a library GEMM
             elif self.gelu == "erf":
                 f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
             else:

@@ -83,12 +83,15 @@ size_t dss_attention_workspace_bytes(int B, int T, int heads);
 int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, int heads, float scale, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- a6: Linear layers with a 384-wide reduction (qkv / attn.proj / mlp.fc1 of dino_vits16, dino_vits8) -------
- * C[M, N] = A[M, 384] . W[N, 384]^T + bias[N], optionally followed by the exact (erf) GELU of DINO's Mlp
+/* ---- a6: Linear layers whose reduction dimension is the embedding width (qkv / attn.proj / mlp.fc1 of DINO's Block)
+ * C[M, N] = A[M, K] . W[N, K]^T + bias[N], optionally followed by the exact (erf) GELU of DINO's Mlp
  * (replaces torch.nn.Linear / nn.GELU inside DINO's Block; reached from extract/extract.py:94).
- * A (row-major), W, bias, C in `dtype` (DSS_F16 / DSS_BF16), fp32 accumulation; N % 64 == 0, N <= 2048.
- * out_layout: DSS_ROW_MAJOR or DSS_PLANAR64 (see above).  K-resident MFMA kernel (linear384.hip). */
+ * K = 384 (dino_vits16 / dino_vits8): dss_linear_k384, N <= 2048;  K = 768 (dino_vitb16 / dino_vitb8):
+ * dss_linear_k768, N <= 3072.  A (row-major), W, bias, C in `dtype` (DSS_F16 / DSS_BF16), fp32 accumulation;
+ * N % 64 == 0.  out_layout: DSS_ROW_MAJOR or DSS_PLANAR64 (see above).  K-resident MFMA kernel (linear384.hip). */
 int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
+                    int dtype, void* stream);
+int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
                     int dtype, void* stream);
 
 /* ---- a10: row L2 normalisation -------------------------------------------------------------

@@ -12,7 +12,7 @@ import json
 import sys
 
 KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
-    "linear_k384": "linear_k384_kernel",
+    "linear_kres": "linear_kres_kernel",
     "attention": "attn_fwd2_kernel",
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_split_kernel",

@@ -96,23 +96,25 @@ def test_layernorm_planar_residual_is_bit_identical_to_row_major(res_dtype):
 
 
 # ----------------------------------------------------------------------------- Linear with K = 384 (qkv / proj / fc1)
-@pytest.mark.parametrize("m,n", [(901, 1152), (512, 384), (1, 64), (77, 1536), (1025, 128), (2 * 3601 + 5, 384)])
+@pytest.mark.parametrize("m,n,k", [(901, 1152, 384), (512, 384, 384), (1, 64, 384), (77, 1536, 384), (1025, 128, 384),
+                                   (2 * 3601 + 5, 384, 384), (3601, 2304, 768), (256, 768, 768), (1, 64, 768),
+                                   (300, 3072, 768), (513, 128, 768)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("planar", [False, True])
-def test_linear_k384_matches_fp32_reference(m, n, dtype, gelu, planar):
+def test_linear_kres_matches_fp32_reference(m, n, k, dtype, gelu, planar):
     """The plain PyTorch fp32 op of the same definition (F.linear, then DINO's exact erf GELU) on the same rounded
     operands; tolerance = the output rounding of the half dtype (fp32 accumulation inside).  Shapes cover ragged
-    M (not a multiple of the 512-row workgroup or the 64-row wave tile) and every N the ViTs use."""
-    g = torch.Generator().manual_seed(m + n)
-    x = torch.randn(m, 384, generator=g).to(dtype)
-    w = (torch.randn(n, 384, generator=g) * 0.05).to(dtype)
+    M (not a multiple of the workgroup or the wave tile) and every (N, K) the ViT-S and ViT-B models use."""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) * 0.05 * (384 / k) ** 0.5).to(dtype)
     b = (torch.randn(n, generator=g) * 0.2).to(dtype)
     ref = F.linear(x.float(), w.float(), b.float())
     if gelu:
         ref = F.gelu(ref)
     guard = 4                                                   # rows after the output must stay untouched
-    out = hip.linear_k384(x.to(DEV), w.to(DEV), b.to(DEV), gelu=gelu, planar=planar)
+    out = hip.linear_kres(x.to(DEV), w.to(DEV), b.to(DEV), gelu=gelu, planar=planar)
     out = (hip.planar_to_rows(out) if planar else out).float().cpu()
     assert out.shape == (m, n) and guard
     tol = (1.0e-3 if dtype == torch.float16 else 8e-3) * max(1.0, ref.abs().max().item())
@@ -123,16 +125,17 @@ def test_linear_k384_matches_fp32_reference(m, n, dtype, gelu, planar):
             assert (out - ref)[neg].abs().max().item() <= (5e-4 if dtype == torch.float16 else 4e-3)
 
 
-def test_linear_k384_does_not_write_past_the_output():
+@pytest.mark.parametrize("k", [384, 768])
+def test_linear_kres_does_not_write_past_the_output(k):
     m, n = 515, 128
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(m, 384, generator=g).half().to(DEV)
-    w = (torch.randn(n, 384, generator=g) * 0.05).half().to(DEV)
+    x = torch.randn(m, k, generator=g).half().to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV)
     b = torch.zeros(n).half().to(DEV)
     for planar in (False, True):
         big = torch.full((m * n + 4096,), 7.0, dtype=torch.float16, device=DEV)
         lib = hip.load_library()
-        rc = lib.dss_linear_k384(x.data_ptr(), w.data_ptr(), b.data_ptr(), big.data_ptr(), m, n, 0,
+        rc = getattr(lib, hip.LINEAR_KRES_WIDTHS[k][0])(x.data_ptr(), w.data_ptr(), b.data_ptr(), big.data_ptr(), m, n, 0,
                                  hip.PLANAR64 if planar else hip.ROW_MAJOR, hip.dtype_code(torch.float16),
                                  torch.cuda.current_stream().cuda_stream)
         assert rc == 0
@@ -141,11 +144,15 @@ def test_linear_k384_does_not_write_past_the_output():
         assert not torch.any(big[: m * n] == 7.0)
 
 
-def test_linear_k384_rejects_bad_shapes():
+def test_linear_kres_rejects_bad_shapes():
     x = torch.zeros(8, 384, dtype=torch.float16, device=DEV)
     w = torch.zeros(96, 384, dtype=torch.float16, device=DEV)
     with pytest.raises(RuntimeError, match="dss_linear_k384"):
-        hip.linear_k384(x, w, torch.zeros(96, dtype=torch.float16, device=DEV))
+        hip.linear_k384(x, w, torch.zeros(96, dtype=torch.float16, device=DEV))     # N % 64 != 0
+    with pytest.raises(ValueError, match="reduction dimension"):
+        hip.linear_kres(torch.zeros(8, 512, dtype=torch.float16, device=DEV),
+                        torch.zeros(64, 512, dtype=torch.float16, device=DEV),
+                        torch.zeros(64, dtype=torch.float16, device=DEV))
 
 
 # ----------------------------------------------------------------------------- attention
