@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
                     help="erf = DINO's GELU (default, the reported configuration); tanh_fused = hipBLASLt epilogue "
                          "(tanh approximation, NOT the reference function; diagnostic only)")
+    ap.add_argument("--vit-streams", type=int, default=1,
+                    help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
+                         "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
+                         "HIP-event durations behind `roofline` then overlap and read long)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the spectral stage of sub-batch i on a side stream under the ViT of sub-batch i+1 "
                          "(measured slower on MI355X: both stages are bandwidth-bound; default off)")
@@ -69,9 +73,10 @@ def parse():
 
 
 _OVERLAP = {}
+_STREAMS = {}
 
 
-def step(model, imgs, K, vit_batch, overlap=False):
+def step(model, imgs, K, vit_batch, overlap=False, nstreams=1):
     """One pass of the hot path over one batch: features + eigs for every image."""
     if overlap:  # spectral stage of sub-batch i on a side stream under the ViT of sub-batch i+1
         key = (id(model), K, vit_batch)
@@ -79,7 +84,19 @@ def step(model, imgs, K, vit_batch, overlap=False):
             _OVERLAP[key] = pipeline.OverlappedExtractor(model, K, vit_batch)
         _, ev, vec, info = _OVERLAP[key](imgs)
         return ev, vec, info
-    ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
+    if nstreams > 1:  # ViT forwards of consecutive sub-batches on alternating streams (opt-in, see --vit-streams)
+        cur = torch.cuda.current_stream()
+        pool = _STREAMS.setdefault(nstreams, [torch.cuda.Stream() for _ in range(nstreams)])
+        ks = []
+        for j, s in enumerate(range(0, imgs.shape[0], vit_batch)):
+            st = pool[j % nstreams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ks.append(model.extract_k(imgs[s:s + vit_batch]))
+        for st in pool:
+            cur.wait_stream(st)
+    else:
+        ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
     k = torch.cat(ks) if len(ks) > 1 else ks[0]
     from dss_amd import spectral
     # strict=False, retry=False: no device->host sync inside the step (convergence is checked once, after timing)
@@ -214,7 +231,7 @@ def main():
     t_warm = time.perf_counter()
     n_warm = 0
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
-        step(model, batch_for(n_warm % max(1, a.warmup)), a.K, a.vit_batch, a.overlap)
+        step(model, batch_for(n_warm % max(1, a.warmup)), a.K, a.vit_batch, a.overlap, a.vit_streams)
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
@@ -230,7 +247,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
-        ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch, a.overlap)
+        ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch, a.overlap, a.vit_streams)
         ids = (torch.arange(a.batch, device=dev) + s * a.batch) * world + rank   # global round-robin item ids
         packed = distributed.pack_results(ids, ev, vec)
         results.append(info)
@@ -283,7 +300,7 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),
         }
         if world == 1 and a.cpu_images > 0:
-            first = step(model, pool[: a.cpu_images + 1], a.K, a.vit_batch, a.overlap)
+            first = step(model, pool[: a.cpu_images + 1], a.K, a.vit_batch, a.overlap, a.vit_streams)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a.model, sd, a.size, a.K, a.cpu_images, first[1], first[0])
         print(json.dumps(out))
     if world > 1:
