@@ -7,10 +7,12 @@ that one Linear's output is kept.  This module computes exactly that tensor and 
 * blocks ``0 .. which_block-1`` run in full; block ``which_block`` runs ``norm1`` and the K rows of its
   qkv Linear only (its attention/proj/MLP and the final norm never influence the hooked tensor;
   SURVEY.md §0.4) - identical output, ~8 % fewer FLOPs for the default ``which_block=-1``.
-* LayerNorm (+ the preceding residual add) and attention are the hand-written HIP kernels of
-  ``libdss_hip.so``; Linear layers are PyTorch-ROCm GEMMs (hipBLASLt) with fp16/bf16 operands and fp32
-  accumulation.  The residual stream, LayerNorm statistics, softmax statistics and the final K
-  projection stay fp32.
+* LayerNorm (+ the preceding residual add), attention and - for the D = 384 models - the qkv / proj /
+  fc1+GELU Linear layers are the hand-written HIP kernels of ``libdss_hip.so`` (the latter exchange
+  activations in the DSS_PLANAR64 layout); the remaining Linear layers (fc2, patch embedding, the last
+  block's K projection, everything at D = 768) are PyTorch-ROCm GEMMs (hipBLASLt).  fp16/bf16 operands,
+  fp32 accumulation everywhere; the residual stream, LayerNorm statistics, softmax statistics and the
+  final K projection stay fp32.
 * the image transform + crop + im2col is one HIP kernel, so the patch embedding is a plain GEMM.
 
 ``state_dict`` keys are those of facebookresearch/dino, so a real DINO checkpoint
@@ -36,7 +38,7 @@ _gemm_tuning_ready = False
 
 
 def setup_gemm_tuning(tune_new_shapes: Optional[bool] = None) -> None:
-    """The dense Linear layers are hipBLASLt GEMMs issued through PyTorch.  PyTorch's TunableOp picks, per GEMM
+    """The Linear layers not covered by ``dss_linear_k384`` are hipBLASLt GEMMs issued through PyTorch.  PyTorch's TunableOp picks, per GEMM
     shape, the fastest hipBLASLt/rocBLAS solution; the table measured on MI355X for the bench shapes ships in
     ``tuning/tunableop_gfx950.csv`` (+5 % end to end over the default heuristic).  Shapes not in the table use
     the default heuristic unless ``tune_new_shapes`` (or ``DSS_GEMM_TUNE=1``) asks for on-line tuning
