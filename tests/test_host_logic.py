@@ -166,3 +166,23 @@ def test_wave_filling_batch_picks_whole_waves_of_workgroups():
             eff = t / (math.ceil(math.ceil(t) / cus) * cus)
             base = (256 * tokens / 512) / (math.ceil(math.ceil(256 * tokens / 512) / cus) * cus)
             assert eff >= base - 1e-9                                    # never worse than the plain target
+
+
+def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp_path):
+    """profiles/r01_pmc_traffic.json (what bench.py reads for roofline.traffic) must follow from the committed
+    rocprofv3 counter summaries: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch."""
+    import json
+    import subprocess
+    import sys
+
+    prof = REPO / "profiles"
+    out = tmp_path / "traffic.json"
+    subprocess.run([sys.executable, str(REPO / "scripts" / "make_pmc_traffic.py"), str(prof / "r01_pmc_FETCH_SIZE.csv"),
+                    str(prof / "r01_pmc_WRITE_SIZE.csv"), str(prof / "r01_bench_n1.json"), str(out)], check=True,
+                   capture_output=True)
+    new, old = json.loads(out.read_text()), json.loads((prof / "r01_pmc_traffic.json").read_text())
+    assert new["config"] == old["config"]
+    for key in ("attention", "layernorm", "laplacian_eigs", "affinity"):
+        assert abs(new["kernels"][key]["hbm_bytes_per_launch"] - old["kernels"][key]["hbm_bytes_per_launch"]) < 1.0
+        k = old["kernels"][key]
+        assert abs((2 * k["fetch_size_kb"] + k["write_size_kb"]) * 1024 - k["hbm_bytes_per_launch"]) < 2048
