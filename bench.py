@@ -116,7 +116,8 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
         if name == "laplacian_eigs":
             n = metas[0]["n"]
             passes = [float(m["info"].abs().sum().item()) for m in metas]
-            byts = np.mean(passes) * 4.0 * n * (n + 1) / 2   # symmetric W: 4*N(N+1)/2 algorithmic bytes per pass
+            wb = metas[0].get("w_bytes", 4)                  # 4 (float W) or 2 (16-bit fixed-point W)
+            byts = np.mean(passes) * wb * n * (n + 1) / 2    # symmetric W: w_bytes*N(N+1)/2 algorithmic bytes per pass
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          passes_per_image=float(np.sum(passes) / sum(m["b"] for m in metas)))
         elif name == "attention":
@@ -128,8 +129,8 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             if os.environ.get("DSS_AFFINITY", "split") == "fp32":   # exact fp32 MFMA build: MFMA-bound
                 flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle: N(N+1)/2 dots of 2D flop
                 entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
-            else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + 2N(N+1) out
-                byts = (4.0 * m["n"] * m["d"] + 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
+            else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
+                byts = (4.0 * m["n"] * m["d"] + m.get("w_bytes", 4) / 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         elif name == "linear_kres":
             # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input)

@@ -64,6 +64,7 @@ static constexpr int GLD = GK + 4;
 __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict__ feats, float* __restrict__ W,
                                                         int N, int D, int ldw, int relu, size_t w_stride,
                                                         int nimg) {
+  typedef float WE;   // storage type of W (the split-f16 kernel below also writes the u16 form)
   __shared__ __attribute__((aligned(16))) float As[GB][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GB][GLD];
   const int tid = threadIdx.x;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
   // epilogue: relu; rows/columns >= N are written as 0 (the matvec relies on it); each half-wave stores 32
   // consecutive floats (128 B) of a tile row.  The whole 64x64 storage tile is always written.
   if (!quad) return;
-  float* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  WE* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
   auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
     const int col = cj0 + csub + li;
 #pragma unroll
@@ -148,7 +149,12 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
       float v = computed ? acc[r] : 0.f;
       if (relu) v = fmaxf(v, 0.f);
       if (row >= N || col >= N) v = 0.f;
-      tile[lr * 64 + csub + li] = v;
+      if constexpr (sizeof(WE) == 4) {
+        tile[lr * 64 + csub + li] = v;
+      } else {
+        const float q = __builtin_rintf(fminf(fmaxf(v, 0.f), 1.0f) * 65535.0f);
+        tile[lr * 64 + csub + li] = (WE)(unsigned)q;
+      }
     }
   };
   store_tile(acc00, 0, 0, act_r0 && act_c0);
@@ -195,8 +201,10 @@ __global__ __launch_bounds__(256) void normalize_rows_split_kernel(const float* 
 static constexpr int SK = 32;        // feature columns per LDS stage (two k16 MFMA steps)
 static constexpr int SLD = SK + 8;   // 80-byte rows: 16 rows land on 16 distinct 16-byte bank slots
 
+// WE = float: W as is.  WE = uint16_t: round(65535 w) clamped to [0, 65535] (relu implied; see eigs_core.h WElem).
+template <class WE>
 __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__ Hi, const f16* __restrict__ Lo,
-                                                         float* __restrict__ W, int N, int D, int ldw, int relu,
+                                                         WE* __restrict__ W, int N, int D, int ldw, int relu,
                                                          size_t w_stride, int nimg) {
   __shared__ __attribute__((aligned(16))) f16 Ah[GB][SLD];
   __shared__ __attribute__((aligned(16))) f16 Al[GB][SLD];
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
   const int I0 = bi * GB, J0 = bj * GB;
   const f16* Hb = Hi + (long)img * N * D;
   const f16* Lb = Lo + (long)img * N * D;
-  float* Wb = W + img * w_stride;
+  WE* Wb = W + img * w_stride;
 
   const int ti = 2 * bi + wr, tj = 2 * bj + wc;
   const bool quad = ti < nt && tj < nt && tj >= ti;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
   }
 
   if (!quad) return;
-  float* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  WE* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
   auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
     const int col = cj0 + csub + li;
 #pragma unroll
@@ -292,7 +300,12 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
       float v = computed ? acc[r] : 0.f;
       if (relu) v = fmaxf(v, 0.f);
       if (row >= N || col >= N) v = 0.f;
-      tile[lr * 64 + csub + li] = v;
+      if constexpr (sizeof(WE) == 4) {
+        tile[lr * 64 + csub + li] = v;
+      } else {
+        const float q = __builtin_rintf(fminf(fmaxf(v, 0.f), 1.0f) * 65535.0f);
+        tile[lr * 64 + csub + li] = (WE)(unsigned)q;
+      }
     }
   };
   store_tile(acc00, 0, 0, act_r0 && act_c0);
@@ -332,8 +345,9 @@ extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, i
   return DSS_OK;
 }
 
-extern "C" int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int normalize, float eps,
-                                  int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream) {
+namespace dss {
+static int affinity_split(const float* feats, void* W, int w_u16, int B, int N, int D, int normalize, float eps,
+                          int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream) {
   DSS_REQUIRE(feats && W && workspace, "dss_affinity_split: null pointer");
   DSS_REQUIRE(B > 0 && N > 0 && D > 0, "dss_affinity_split: bad shape B=%d N=%d D=%d", B, N, D);
   DSS_REQUIRE(D % dss::SK == 0, "dss_affinity_split: feature dim must be a multiple of %d (got %d)", dss::SK, D);
@@ -353,10 +367,27 @@ extern "C" int dss_affinity_split(const float* feats, float* W, int B, int N, in
   const int nbk = (ldw / 64 + 1) / 2;
   const long nblocks = (long)(nbk * (nbk + 1) / 2) * B;
   DSS_REQUIRE(nblocks < 2147483647L, "dss_affinity_split: too many blocks (%ld)", nblocks);
-  hipLaunchKernelGGL(dss::gram_split_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, hi, lo, W, N, D, ldw,
-                     threshold_at_zero ? 1 : 0, dss_affinity_elems(N), B);
+  if (w_u16)
+    hipLaunchKernelGGL(dss::gram_split_kernel<uint16_t>, dim3((unsigned)nblocks), dim3(256), 0, s, hi, lo,
+                       (uint16_t*)W, N, D, ldw, 1, dss_affinity_elems(N), B);
+  else
+    hipLaunchKernelGGL(dss::gram_split_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, s, hi, lo, (float*)W, N,
+                       D, ldw, threshold_at_zero ? 1 : 0, dss_affinity_elems(N), B);
   DSS_CHECK_LAUNCH("gram_split");
   return DSS_OK;
+}
+
+}  // namespace dss
+
+extern "C" int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int normalize, float eps,
+                                  int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::affinity_split(feats, W, 0, B, N, D, normalize, eps, threshold_at_zero, workspace, workspace_bytes,
+                             stream);
+}
+
+extern "C" int dss_affinity_split_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::affinity_split(feats, W, 1, B, N, D, 1, eps, 1, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t dss_affinity_split_workspace_bytes(int B, int N, int D) {

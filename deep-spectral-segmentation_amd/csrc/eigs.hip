@@ -9,7 +9,8 @@ namespace dss {
 
 static constexpr int EIGS_THREADS = 1024;  // upper bound of the launch (register budget: 128 VGPRs)
 
-__global__ __launch_bounds__(EIGS_THREADS) void laplacian_eigs_kernel(const float* __restrict__ W, EigsParams P,
+template <class WE>
+__global__ __launch_bounds__(EIGS_THREADS) void laplacian_eigs_kernel(const WE* __restrict__ W, EigsParams P,
                                                                       float* gws, size_t gws_stride,
                                                                       float* eigenvalues, float* eigenvectors,
                                                                       int32_t* info) {
@@ -50,50 +51,69 @@ extern "C" size_t dss_eigs_workspace_bytes(int B, int N, int K, int ncv) {
   return (size_t)B * dss::eigs_ws_floats_per_image(dss_affinity_ld(N), ncv) * sizeof(float);
 }
 
-extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
-                                  int32_t* info, int ncv, float tol, int max_restarts, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
-  return dss_symmetric_eigs(W, B, N, K, DSS_EIGS_NORMALIZED_LAPLACIAN, eigenvalues, eigenvectors, info, ncv, tol,
-                            max_restarts, workspace, workspace_bytes, stream);
-}
+namespace dss {
 
-extern "C" int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode, float* eigenvalues,
-                                  float* eigenvectors, int32_t* info, int ncv, float tol, int max_restarts,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+template <class WE>
+static int symmetric_eigs(const WE* W, int B, int N, int K, int mode, float* eigenvalues, float* eigenvectors,
+                          int32_t* info, int ncv, float tol, int max_restarts, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   DSS_REQUIRE(W && eigenvalues && eigenvectors && info && workspace, "dss_laplacian_eigs: null pointer");
   DSS_REQUIRE(mode == DSS_EIGS_NORMALIZED_LAPLACIAN || mode == DSS_EIGS_AFFINITY_LM || mode == DSS_EIGS_LAPLACIAN,
               "dss_symmetric_eigs: unknown mode %d", mode);
   DSS_REQUIRE(B > 0 && N > 1 && K > 0, "dss_laplacian_eigs: bad shape B=%d N=%d K=%d", B, N, K);
   DSS_REQUIRE(K < N, "dss_laplacian_eigs: need K < N (K=%d, N=%d)", K, N);
-  ncv = dss::resolve_ncv(N, K, ncv);
+  ncv = resolve_ncv(N, K, ncv);
   DSS_REQUIRE(ncv >= K + 2 || ncv == N,
-              "dss_laplacian_eigs: Krylov dimension %d too small for K=%d (max %d)", ncv, K, dss::EIGS_MAX_NCV);
+              "dss_laplacian_eigs: Krylov dimension %d too small for K=%d (max %d)", ncv, K, EIGS_MAX_NCV);
   const int ld = dss_affinity_ld(N);
-  const size_t per_img = dss::eigs_ws_floats_per_image(ld, ncv);
+  const size_t per_img = eigs_ws_floats_per_image(ld, ncv);
   if (workspace_bytes < (size_t)B * per_img * sizeof(float))
-    return dss::fail(DSS_ERR_WORKSPACE, "dss_laplacian_eigs: workspace %zu < %zu bytes", workspace_bytes,
-                     (size_t)B * per_img * sizeof(float));
-  dss::EigsParams P;
+    return fail(DSS_ERR_WORKSPACE, "dss_laplacian_eigs: workspace %zu < %zu bytes", workspace_bytes,
+                (size_t)B * per_img * sizeof(float));
+  EigsParams P;
   P.N = N; P.ld = ld; P.K = K; P.ncv = ncv;
   P.keep = (ncv + K) / 2;  // tuned on tests/golden with the host emulation (tests/host_emul)
   P.max_restarts = max_restarts > 0 ? max_restarts : 60;
   P.tol = tol > 0.f ? tol : 2e-6f;
   P.mode = mode;
-  const dss::EigsLds L = dss::eigs_lds_layout(ld, ncv);
+  const EigsLds L = eigs_lds_layout(ld, ncv);
   DSS_REQUIRE(L.total <= 160 * 1024, "dss_laplacian_eigs: N=%d needs %zu B of LDS (> 160 KiB)", N, L.total);
-  hipError_t e = hipFuncSetAttribute((const void*)dss::laplacian_eigs_kernel,
+  hipError_t e = hipFuncSetAttribute((const void*)laplacian_eigs_kernel<WE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
   if (e != hipSuccess)
-    return dss::fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
+    return fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
   // 512-thread workgroups (default) let two images share a CU: the serial Rayleigh-Ritz / restart phases of one
   // overlap the W streaming of the other.  DSS_EIGS_THREADS=1024 selects one 16-wave workgroup per CU.
   const char* env = getenv("DSS_EIGS_THREADS");
   int threads = env ? atoi(env) : 512;
   if (threads != 256 && threads != 512 && threads != 1024) threads = 512;
-  hipLaunchKernelGGL(dss::laplacian_eigs_kernel, dim3(B), dim3(threads), L.total, (hipStream_t)stream,
-                     W, P, (float*)workspace, per_img, eigenvalues, eigenvectors, info);
+  hipLaunchKernelGGL(laplacian_eigs_kernel<WE>, dim3(B), dim3(threads), L.total, (hipStream_t)stream, W, P,
+                     (float*)workspace, per_img, eigenvalues, eigenvectors, info);
   DSS_CHECK_LAUNCH("laplacian_eigs");
   return DSS_OK;
+}
+
+}  // namespace dss
+
+extern "C" int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
+                                  int32_t* info, int ncv, float tol, int max_restarts, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return dss::symmetric_eigs<float>(W, B, N, K, DSS_EIGS_NORMALIZED_LAPLACIAN, eigenvalues, eigenvectors, info, ncv,
+                                    tol, max_restarts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dss_laplacian_eigs_u16(const uint16_t* W, int B, int N, int K, float* eigenvalues,
+                                      float* eigenvectors, int32_t* info, int ncv, float tol, int max_restarts,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::symmetric_eigs<uint16_t>(W, B, N, K, DSS_EIGS_NORMALIZED_LAPLACIAN, eigenvalues, eigenvectors, info,
+                                       ncv, tol, max_restarts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode, float* eigenvalues,
+                                  float* eigenvectors, int32_t* info, int ncv, float tol, int max_restarts,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::symmetric_eigs<float>(W, B, N, K, mode, eigenvalues, eigenvectors, info, ncv, tol, max_restarts,
+                                    workspace, workspace_bytes, stream);
 }
 
 extern "C" int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream) {

@@ -160,7 +160,16 @@ DSS_DEV float hash_unit(uint32_t e) {  // deterministic start vector entry in [-
 // which every lane owns exactly one finished row sum and one column sum) and added to the LDS accumulator with one
 // ds_add_f32 per lane.  (Floating-point LDS atomics: the accumulation order across waves is not fixed, so results
 // are reproducible to rounding, not bitwise.)   xs must be zero beyond N.  Barriers inside.
-DSS_DEV void matvec_sym(const float* __restrict__ Wp, int N, int ld, const float* xs, float* ws, const float* dis,
+// Storage type of W.  float: the values themselves.  uint16_t: round(65535 w), w in [0, 1] (normalised features,
+// thresholded at zero): the normalised-Laplacian problem is invariant to the scale of W, a uniform 7.6e-6 absolute
+// step perturbs the eigenvectors of the goldens by <= 1e-6 in cosine (<= 1e-7 for the K=5 cases; an f16 W would cost
+// 1e-5 .. 6e-4), and the matvec - the only HBM stream of the solver - moves half the bytes.
+template <class WE> struct WElem;
+template <> struct WElem<float> { static constexpr float scale = 1.0f; };
+template <> struct WElem<uint16_t> { static constexpr float scale = 65535.0f; };
+
+template <class WE>
+DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* xs, float* ws, const float* dis,
                         bool scale) {
   const int nt = ld / WT;
   for (int e = DSS_TID; e < ld; e += DSS_NT) ws[e] = 0.f;
@@ -168,16 +177,16 @@ DSS_DEV void matvec_sym(const float* __restrict__ Wp, int N, int ld, const float
 #ifdef DSS_HOST_EMUL
   for (int I = 0; I < nt; ++I)
     for (int J = I; J < nt; ++J) {
-      const float* A = Wp + (size_t)(wsym_row_start(I, nt) + (J - I)) * WT * WT;
+      const WE* A = Wp + (size_t)(wsym_row_start(I, nt) + (J - I)) * WT * WT;
       for (int r = 0; r < WT; ++r) {
         float acc = 0.f;
-        for (int c = 0; c < WT; ++c) acc += A[r * WT + c] * xs[J * WT + c];
+        for (int c = 0; c < WT; ++c) acc += (float)A[r * WT + c] * xs[J * WT + c];
         ws[I * WT + r] += acc;
       }
       if (I != J)
         for (int c = 0; c < WT; ++c) {
           float acc = 0.f;
-          for (int r = 0; r < WT; ++r) acc += A[r * WT + c] * xs[I * WT + r];
+          for (int r = 0; r < WT; ++r) acc += (float)A[r * WT + c] * xs[I * WT + r];
           ws[J * WT + c] += acc;
         }
     }
@@ -189,10 +198,25 @@ DSS_DEV void matvec_sym(const float* __restrict__ Wp, int N, int ld, const float
   for (int t = DSS_WAVE; t < ntiles; t += DSS_NWAVES) {
     while (t >= row_start + (nt - I)) { row_start += nt - I; ++I; }
     const int J = I + (t - row_start);
-    const f32x4* A4 = reinterpret_cast<const f32x4*>(Wp + (size_t)t * WT * WT);
     f32x4 a[16];
+    if constexpr (sizeof(WE) == 4) {
+      const f32x4* A4 = reinterpret_cast<const f32x4*>(Wp + (size_t)t * WT * WT);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = __builtin_nontemporal_load(A4 + k * 64 + lane);
+      for (int k = 0; k < 16; ++k) a[k] = __builtin_nontemporal_load(A4 + k * 64 + lane);
+    } else {  // 4 x u16 per lane per row group: same (row, column) ownership as the float path, 8-byte loads
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2* A2 = reinterpret_cast<const u32x2*>(Wp + (size_t)t * WT * WT);
+      u32x2 raw[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) raw[k] = __builtin_nontemporal_load(A2 + k * 64 + lane);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        a[k][0] = (float)(raw[k][0] & 0xffffu);
+        a[k][1] = (float)(raw[k][0] >> 16);
+        a[k][2] = (float)(raw[k][1] & 0xffffu);
+        a[k][3] = (float)(raw[k][1] >> 16);
+      }
+    }
     const f32x4 xj = *reinterpret_cast<const f32x4*>(xs + J * WT + 4 * q);
     float rp[16];
 #pragma unroll
@@ -393,7 +417,8 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
 //   gws        global workspace of eigs_ws_floats_per_image(ld, ncv) floats
 //   lds        LDS block of eigs_lds_layout(ld, ncv).total bytes (16-byte aligned)
 //   eigenvalues[K], eigenvectors[K, N] outputs; *info = +passes (converged) / -passes (budget exhausted)
-DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, float* gws, unsigned char* lds,
+template <class WE>
+DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float* gws, unsigned char* lds,
                             float* eigenvalues, float* eigenvectors, int32_t* info) {
   const int N = P.N, ld = P.ld, K = P.K, mmax = P.ncv;
   const EigsLds L = eigs_lds_layout(ld, mmax);
@@ -538,6 +563,7 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
 
   // ---- Ritz vectors -> generalized eigenvectors v = D^-1/2 u, sign rule, eigenvalues ----------------------
   DSS_SYNC();
+  const float vscale = sqrtf(WElem<WE>::scale);
   float* Zf = reinterpret_cast<float*>(A);
   for (int idx = DSS_TID; idx < m * K; idx += DSS_NT) {
     const int i = idx / m, j = idx - i * m;
@@ -549,7 +575,8 @@ DSS_DEV void eigs_one_image(const float* __restrict__ W, const EigsParams P, flo
     for (int e = DSS_TID; e < N; e += DSS_NT) {
       float u = 0.f;
       for (int j = 0; j < m; ++j) u += Va[(size_t)j * ldv + e] * Zf[(size_t)i * m + j];
-      const float v = mode == EIGS_NORMALIZED_LAPLACIAN ? u * dis[e] : u;
+      // D was accumulated in storage units (scale * true degree): v^T D_true v = 1 needs the sqrt(scale) back
+      const float v = mode == EIGS_NORMALIZED_LAPLACIAN ? u * dis[e] * vscale : u;
       ws[e] = v;
       pos += v > 0.f ? 1 : 0;
     }

@@ -40,7 +40,10 @@ SYMBOLS = {
     "dss_affinity_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dss_affinity_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
                                    c_void_p]),
+    "dss_affinity_split_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dss_laplacian_eigs_u16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                       c_int, c_void_p, c_size_t, c_void_p]),
     "dss_laplacian_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_int, c_void_p, c_size_t, c_void_p]),
     "dss_symmetric_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
@@ -261,6 +264,8 @@ def affinity_to_dense(wp: torch.Tensor, n: int) -> torch.Tensor:
     ld = affinity_ld(n)
     nt = ld // 64
     b = wp.shape[0]
+    if wp.dtype == torch.int16:   # the 16-bit fixed-point form (uint16 bits in an int16 container): w = q / 65535
+        wp = (wp.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535.0
     tiles = wp.reshape(b, -1, 64, 64)
     dense = torch.zeros((b, ld, ld), dtype=wp.dtype, device=wp.device)
     t = 0
@@ -286,16 +291,26 @@ def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tenso
 
 
 def affinity_split(feats: torch.Tensor, normalize: bool = True, threshold_at_zero: bool = True,
-                   eps: float = 1e-12) -> torch.Tensor:
+                   eps: float = 1e-12, u16: bool = False) -> torch.Tensor:
     """RAW f32 ``[B, N, D]`` features -> packed ``W`` like ``affinity(normalize_rows(feats))`` but on the f16 MFMA
-    path with a two-term split of every feature (fp32-class accuracy, HBM-bound instead of fp32-MFMA-bound)."""
+    path with a two-term split of every feature (fp32-class accuracy, HBM-bound instead of fp32-MFMA-bound).
+    ``u16``: store ``round(65535 w)`` (needs ``normalize`` and ``threshold_at_zero``: ``w`` in [0, 1]) in an int16
+    container - the form ``laplacian_eigs`` streams at half the bytes."""
     assert feats.dtype == torch.float32 and feats.dim() == 3
     b, n, d = feats.shape
     lib = load_library()
-    w = torch.empty((b, affinity_elems(n)), dtype=torch.float32, device=feats.device)
     need = int(lib.dss_affinity_split_workspace_bytes(b, n, d))
     ws = torch.empty(need, dtype=torch.uint8, device=feats.device)
-    with _timed("affinity", b=b, n=n, d=d):
+    if u16:
+        if not (normalize and threshold_at_zero):
+            raise ValueError("the 16-bit fixed-point W needs normalize=True and threshold_at_zero=True (w in [0, 1])")
+        w = torch.empty((b, affinity_elems(n)), dtype=torch.int16, device=feats.device)
+        with _timed("affinity", b=b, n=n, d=d, w_bytes=2):
+            _check(lib.dss_affinity_split_u16(_dev(feats, "feats"), _dev(w, "W"), b, n, d, float(eps), _dev(ws, "ws"),
+                                              need, _stream()), "dss_affinity_split_u16")
+        return w
+    w = torch.empty((b, affinity_elems(n)), dtype=torch.float32, device=feats.device)
+    with _timed("affinity", b=b, n=n, d=d, w_bytes=4):
         _check(lib.dss_affinity_split(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(normalize), float(eps),
                                       int(threshold_at_zero), _dev(ws, "ws"), need, _stream()), "dss_affinity_split")
     return w
@@ -308,7 +323,10 @@ def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0
                    workspace: Optional[torch.Tensor] = None, mode: int = EIGS_NORMALIZED_LAPLACIAN):
     """packed ``W`` ``[B, affinity_elems(N)]`` -> (eigenvalues ``[B, K]``, eigenvectors ``[B, K, N]``, info ``[B]``).
     ``mode``: the problem solved on W (``dss_symmetric_eigs``); pairs come back in the solver's ranking order."""
-    assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == affinity_elems(n)
+    assert w.dtype in (torch.float32, torch.int16) and w.dim() == 2 and w.shape[1] == affinity_elems(n)
+    u16 = w.dtype == torch.int16
+    if u16 and mode != EIGS_NORMALIZED_LAPLACIAN:
+        raise ValueError("the 16-bit fixed-point W is only valid for the (scale-invariant) normalised Laplacian")
     b = w.shape[0]
     lib = load_library()
     need = int(lib.dss_eigs_workspace_bytes(b, n, k, ncv))
@@ -317,11 +335,17 @@ def laplacian_eigs(w: torch.Tensor, n: int, k: int, ncv: int = 0, tol: float = 0
     evals = torch.empty((b, k), dtype=torch.float32, device=w.device)
     evecs = torch.empty((b, k, n), dtype=torch.float32, device=w.device)
     info = torch.zeros((b,), dtype=torch.int32, device=w.device)
-    with _timed("laplacian_eigs", b=b, n=n, k=k, info=info):
-        _check(lib.dss_symmetric_eigs(_dev(w, "W"), b, n, k, int(mode), _dev(evals, "evals"), _dev(evecs, "evecs"),
-                                      _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
-                                      workspace.numel() * workspace.element_size(), _stream()),
-               "dss_symmetric_eigs")
+    with _timed("laplacian_eigs", b=b, n=n, k=k, info=info, w_bytes=2 if u16 else 4):
+        if u16:
+            _check(lib.dss_laplacian_eigs_u16(_dev(w, "W"), b, n, k, _dev(evals, "evals"), _dev(evecs, "evecs"),
+                                              _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
+                                              workspace.numel() * workspace.element_size(), _stream()),
+                   "dss_laplacian_eigs_u16")
+        else:
+            _check(lib.dss_symmetric_eigs(_dev(w, "W"), b, n, k, int(mode), _dev(evals, "evals"), _dev(evecs, "evecs"),
+                                          _dev(info, "info"), ncv, float(tol), max_restarts, _dev(workspace, "ws"),
+                                          workspace.numel() * workspace.element_size(), _stream()),
+                   "dss_symmetric_eigs")
     return evals, evecs, info
 
 

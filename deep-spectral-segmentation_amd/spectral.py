@@ -58,7 +58,9 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
       ``image_downsample_factor != patch_size`` (extract.py:179-188): the (already normalised) features are resized
       bilinearly (``align_corners=False``) from the patch grid to the low-resolution pixel grid before the affinity.
     * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
-      (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.
+      (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.  With the default recipe (``problem="laplacian"``,
+      ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``$DSS_W_DTYPE=f32`` keeps
+      floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
       Checking for them reads ``info`` back (one device->host sync per call): throughput loops that must keep
       the host running ahead pass ``retry=False, strict=False`` and inspect ``info`` once at the end.
@@ -91,8 +93,13 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         raise ValueError(f"unknown problem {problem!r}")
     if problem == "affinity_svd":
         threshold_at_zero = False  # the singular vectors of F are the eigenvectors of the UN-thresholded F F^T
+    # W as 16-bit fixed point (half the bytes of the solver's only HBM stream) whenever the problem allows it: the
+    # normalised Laplacian is invariant to the scale of W, and normalised + thresholded similarities lie in [0, 1]
+    # (after an upsample the rows are interpolated, not re-normalised: |w| <= 1 still holds, but keep f32 there).
+    w_u16 = (problem == "laplacian" and normalize and threshold_at_zero and upsample is None and d % 32 == 0
+             and affinity_mode == "split" and os.environ.get("DSS_W_DTYPE", "u16") == "u16")
     ld = hip.affinity_ld(n)
-    per_image = hip.affinity_elems(n) * 4 + 2 * 66 * ld * 4
+    per_image = hip.affinity_elems(n) * (2 if w_u16 else 4) + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
     evals, evecs, infos = [], [], []
     for s in range(0, b, chunk):
@@ -102,7 +109,7 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
                 f = hip.normalize_rows(f)
             w = hip.affinity(f, threshold_at_zero)
         else:  # split-f16 (fp32-class accuracy, ~1e-7), HBM-bound; fused with the row normalisation
-            w = hip.affinity_split(f, normalize, threshold_at_zero)
+            w = hip.affinity_split(f, normalize, threshold_at_zero, u16=w_u16)
         ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts,
                                            mode=_PROBLEM_MODE[problem])
         evals.append(ev), evecs.append(vec), infos.append(info)

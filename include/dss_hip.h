@@ -120,6 +120,12 @@ int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshol
 size_t dss_affinity_split_workspace_bytes(int B, int N, int D);
 int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int normalize, float eps,
                        int threshold_at_zero, void* workspace, size_t workspace_bytes, void* stream);
+/* The default recipe (normalize = True, threshold_at_zero = True) with W stored as 16-bit fixed point:
+ * W_q = round(65535 w), w in [0, 1], same packed tile layout, dss_affinity_elems(N) uint16 per image - half the
+ * bytes of the only HBM stream of the eigensolver.  The normalised-Laplacian eigenproblem does not depend on the scale
+ * of W; the uniform 7.6e-6 quantisation step moves the eigenvectors of the reference goldens by <= 1e-6 in cosine. */
+int dss_affinity_split_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- a13-a15: degree, normalised Laplacian, K smallest generalized eigenpairs, sign rule -------
  * extract/extract_utils.py:207-220  d = W 1 ; d[d < 1e-12] = 1
@@ -138,6 +144,11 @@ size_t dss_eigs_workspace_bytes(int B, int N, int K, int ncv);
 int dss_laplacian_eigs(const float* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
                        int32_t* info, int ncv, float tol, int max_restarts,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Same solver on the W written by dss_affinity_split_u16 (outputs in the reference's units: v^T D v = 1 with the
+ * true degrees). */
+int dss_laplacian_eigs_u16(const uint16_t* W, int B, int N, int K, float* eigenvalues, float* eigenvectors,
+                           int32_t* info, int ncv, float tol, int max_restarts,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same solver on the other two problems of the reference's _extract_eig (same W layout, same outputs' shapes,
  * pairs returned in the solver's ranking order; the sign rule is applied to every vector):

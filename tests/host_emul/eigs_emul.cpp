@@ -10,10 +10,11 @@
 
 #include "../../deep-spectral-segmentation_amd/csrc/eigs_core.h"
 
-// W: packed upper-triangular 64x64 tiles (csrc/eigs_core.h wsym_*), wsym_floats(ld) floats per image.
-extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int K, float* eigenvalues,
-                                       float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
-                                       int max_restarts, int mode) {
+// W: packed upper-triangular 64x64 tiles (csrc/eigs_core.h wsym_*), wsym_floats(ld) elements per image; WE = float
+// (the values) or uint16_t (round(65535 w), the default storage of the product path).
+template <class WE>
+static int emul(const WE* W, int B, int N, int ld, int K, float* eigenvalues, float* eigenvectors, int32_t* info,
+                int ncv, int keep, float tol, int max_restarts, int mode) {
   using namespace dss;
   if (ncv > EIGS_MAX_NCV) ncv = EIGS_MAX_NCV;
   if (ncv > N) ncv = N;
@@ -30,4 +31,16 @@ extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int
                    eigenvectors + (size_t)b * K * N, info + b);
   }
   return 0;
+}
+
+extern "C" int dss_emul_laplacian_eigs(const float* W, int B, int N, int ld, int K, float* eigenvalues,
+                                       float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
+                                       int max_restarts, int mode) {
+  return emul<float>(W, B, N, ld, K, eigenvalues, eigenvectors, info, ncv, keep, tol, max_restarts, mode);
+}
+
+extern "C" int dss_emul_laplacian_eigs_u16(const uint16_t* W, int B, int N, int ld, int K, float* eigenvalues,
+                                           float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
+                                           int max_restarts) {
+  return emul<uint16_t>(W, B, N, ld, K, eigenvalues, eigenvectors, info, ncv, keep, tol, max_restarts, 0);
 }

@@ -242,6 +242,16 @@ def test_affinity_matches_fp64(b, n, d):
     assert (ws[:, :n, :n].double() - ref).abs().max().item() < 2e-6
     # symmetric to rounding only: inside a diagonal tile the two cross terms accumulate in the opposite order
     assert (ws - ws.transpose(1, 2)).abs().max().item() < 2e-7
+    # 16-bit fixed-point storage (default of the spectral stage for the scale-invariant problem): round(65535 w)
+    wq_packed = hip.affinity_split(feats.to(DEV), u16=True)
+    assert wq_packed.dtype == torch.int16 and wq_packed.shape == wp.shape
+    wq = hip.affinity_to_dense(wq_packed, n).cpu()
+    assert torch.equal(wq[:, :, n:], torch.zeros(b, ld, ld - n)) and torch.equal(wq[:, n:, :], torch.zeros(b, ld - n, ld))
+    assert (wq[:, :n, :n].double() - ref).abs().max().item() <= 0.5 / 65535 + 2e-6     # half a quantisation step
+    assert wq.min().item() >= 0.0 and wq.max().item() <= 1.0
+    assert abs(wq[0, 0, 0].item() - 1.0) < 1e-6                                         # w_ii = 1 -> 65535 exactly
+    with pytest.raises(ValueError, match="16-bit"):
+        hip.affinity_split(feats.to(DEV), threshold_at_zero=False, u16=True)
     wsn = hip.affinity_to_dense(hip.affinity_split(feats.to(DEV), threshold_at_zero=False), n).cpu()
     assert (wsn[:, :n, :n].double() - x @ x.transpose(1, 2)).abs().max().item() < 2e-6
     raw = feats.to(DEV) * 0.37   # un-normalised features (normalize=False path)
@@ -254,8 +264,10 @@ def test_affinity_matches_fp64(b, n, d):
 EIG_FILES = sorted(glob.glob(str(HERE / "golden" / "eigs_*.npz")))
 
 
+@pytest.mark.parametrize("w_dtype", ["u16", "f32"])   # storage of W: 16-bit fixed point (default) or floats
 @pytest.mark.parametrize("path", EIG_FILES, ids=lambda p: p.split("eigs_")[-1][:-4])
-def test_eigs_match_reference_goldens(path):
+def test_eigs_match_reference_goldens(path, w_dtype, monkeypatch):
+    monkeypatch.setenv("DSS_W_DTYPE", w_dtype)
     feats, K, ref_lam, ref_vec, _ = golden_case(path)
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
     assert info.item() > 0
@@ -266,6 +278,24 @@ def test_eigs_match_reference_goldens(path):
         assert d_orthonormality(vec[0].cpu().numpy(), d=d) < 1e-4  # v^T D v = 1 like ARPACK with M=D
     for k in range(K):
         assert not (0.5 < (vec[0, k] > 0).float().mean().item() < 1.0)  # sign-rule post-condition
+
+
+def test_eigs_u16_storage_agrees_with_float_storage(monkeypatch):
+    """Same images through both storages of W: eigenvalues within 3e-6, eigenvectors within 3e-6 in cosine (the
+    quantisation step of 1/65535 is far below the 1e-4 parity budget), identical sign decisions."""
+    n, d, K, b = 900, 384, 5, 6
+    feats = torch.from_numpy(np.stack([synthetic.synthetic_features("blobs" if i % 2 else "random", n, d, 70 + i)
+                                       for i in range(b)])).to(DEV)
+    out = {}
+    for w_dtype in ("u16", "f32"):
+        monkeypatch.setenv("DSS_W_DTYPE", w_dtype)
+        out[w_dtype] = spectral.laplacian_eigs_from_features(feats, K)
+        assert (out[w_dtype][2] > 0).all()
+    assert (out["u16"][0] - out["f32"][0]).abs().max().item() < 3e-6
+    a, c = out["u16"][1].double(), out["f32"][1].double()
+    cos = (a * c).sum(-1) / (a.norm(dim=-1) * c.norm(dim=-1))
+    assert (1 - cos).max().item() < 3e-6          # signed cosine: the sign rule made the same decisions
+    assert ((a.norm(dim=-1) / c.norm(dim=-1)) - 1).abs().max().item() < 1e-4   # same normalisation (v^T D v = 1)
 
 
 @pytest.mark.parametrize("mode", ["split", "fp32"])

@@ -24,6 +24,9 @@ def emul(tmp_path_factory):
     lib = ctypes.CDLL(str(out))
     lib.dss_emul_laplacian_eigs.argtypes = [FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, FP, FP, IP,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    lib.dss_emul_laplacian_eigs_u16.argtypes = [ctypes.POINTER(ctypes.c_uint16), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, FP, FP, IP, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_int]
     return lib
 
 
@@ -37,7 +40,7 @@ def pack_sym(w, ld):
     return np.ascontiguousarray(np.concatenate(tiles))
 
 
-def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, threshold=True):
+def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, threshold=True, u16=False):
     x = feats / np.maximum(np.linalg.norm(feats, axis=1, keepdims=True), 1e-12)
     x = x.astype(np.float32)
     w = x @ x.T
@@ -49,6 +52,13 @@ def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, th
     ncv = ncv or min(max(2 * K + 10, 20), 64, n)
     keep = keep or (ncv + K) // 2
     ev, vec, info = np.zeros(K, np.float32), np.zeros((K, n), np.float32), np.zeros(1, np.int32)
+    if u16:  # the product path's storage: round(65535 w), w in [0, 1]
+        assert threshold and mode == 0
+        wq = np.ascontiguousarray(np.rint(np.clip(wp, 0.0, 1.0) * 65535.0).astype(np.uint16))
+        lib.dss_emul_laplacian_eigs_u16(wq.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), 1, n, ld, K,
+                                        ev.ctypes.data_as(FP), vec.ctypes.data_as(FP), info.ctypes.data_as(IP), ncv,
+                                        keep, tol, max_restarts)
+        return ev, vec, int(info[0])
     lib.dss_emul_laplacian_eigs(wp.ctypes.data_as(FP), 1, n, ld, K, ev.ctypes.data_as(FP), vec.ctypes.data_as(FP),
                                 info.ctypes.data_as(IP), ncv, keep, tol, max_restarts, mode)
     return ev, vec, int(info[0])
@@ -57,10 +67,13 @@ def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, th
 CASES = [p for p in sorted(glob.glob(str(HERE / "golden" / "eigs_*.npz"))) if "3600" not in p]
 
 
+@pytest.mark.parametrize("u16", [False, True], ids=["w_f32", "w_u16"])
 @pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("eigs_")[-1][:-4])
-def test_kernel_logic_matches_reference_goldens(emul, path):
+def test_kernel_logic_matches_reference_goldens(emul, path, u16):
+    """u16: W quantised to 16-bit fixed point as the product path stores it - same tolerance against the reference's
+    own outputs (the quantisation moves the eigenvectors by <= 1e-6 in cosine), same D-orthonormality in TRUE units."""
     feats, K, ref_lam, ref_vec, _ = golden_case(path)
-    lam, vec, info = run_emul(emul, feats, K)
+    lam, vec, info = run_emul(emul, feats, K, u16=u16)
     assert info > 0, f"not converged (info={info})"
     check_eigs(vec, lam, ref_vec, ref_lam, what=path)
     _, d = build_w64(feats)
