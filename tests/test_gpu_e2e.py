@@ -34,6 +34,22 @@ def test_vit_features_match_oracle(dtype, tol, h, w):
         assert rel < tol, rel
 
 
+@pytest.mark.parametrize("env", [{"DSS_MLP_FUSED": "1"}, {"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"},
+                                 {"DSS_LINEAR_K384": "3"}])
+def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
+    """The non-default ways through the ViT (fused Mlp kernel; library GEMMs only; K-resident qkv/proj only; the
+    K = 768 kernel forced for ViT-B) against the fp32 oracle ViT, same bar as the default path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    name = "dino_vitb16" if env.get("DSS_LINEAR_K384") == "3" else "dino_vits16"
+    model, ref = _models(name, 7, 0.05, torch.float16)
+    imgs = np.stack([synthetic.synthetic_image(20 + i, 100, 130) for i in range(2)])
+    k = model.extract_k(torch.from_numpy(imgs).to(DEV)).cpu()
+    for i in range(2):
+        kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(imgs[i]))[0]
+        assert ((k[i] - kr).norm() / kr.norm()).item() < 4e-3
+
+
 def test_vit_patch8_and_which_block():
     model, ref = _models("dino_vitb8", 2, 0.05, torch.float16)
     img = synthetic.synthetic_image(5, 64, 88)
