@@ -219,8 +219,8 @@ class DinoViT:
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
             if self.mlp_fused and d == 384 and self.gelu == "erf":
                 if "fc2_wp" not in blk:
-                    blk["fc2_wp"] = hip.mlp_k384_pack_fc2(blk["fc2_w"])
-                pending = hip.mlp_k384(hcur, blk["fc1_w"], blk["fc1_b"], blk["fc2_wp"], blk["fc2_b"])
+                    blk["fc1_wp"], blk["fc2_wp"] = hip.mlp_k384_pack(blk["fc1_w"], blk["fc2_w"])
+                pending = hip.mlp_k384(hcur, blk["fc1_wp"], blk["fc1_b"], blk["fc2_wp"], blk["fc2_b"])
                 continue
             if kres_fc1:
                 f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)        # row-major: fc2 is a library GEMM
