@@ -43,7 +43,7 @@ REFERENCE = Path("/root/reference")
 GOLDEN = REPO / "tests" / "golden"
 sys.path.insert(0, str(REPO))
 
-from oracle import vit_ref  # noqa: E402
+from oracle import spectral_ref, vit_ref  # noqa: E402
 import dss_amd as dss  # noqa: E402
 
 synthetic = dss.synthetic
@@ -152,13 +152,38 @@ def make_eig_goldens(ref):
             ref._extract_eig((0, str(fdir / f"{name}.pth")), K=K, images_root="", output_dir=str(odir),
                              image_color_lambda=0.0)
             out = torch.load(odir / f"{name}.pth", map_location="cpu", weights_only=False)
-        ev, evec = out["eigenvalues"], out["eigenvectors"]
-        assert evec.dtype == torch.float32 and tuple(evec.shape) == (K, n), (evec.dtype, evec.shape)
+            ev, evec = out["eigenvalues"], out["eigenvectors"]
+            assert evec.dtype == torch.float32 and tuple(evec.shape) == (K, n), (evec.dtype, evec.shape)
+            # the reference's fp32 ARPACK run has heavy-tailed run-to-run noise (oracle/spectral_ref.py,
+            # ref_laplacian_eigs_ext): record how far THIS run is from the fp64 solution of the same problem and
+            # re-draw a run whose isolated vectors are further than 1e-5 away, so the fixture is a typical output
+            lam64, v64 = spectral_ref.dense_f64_eigs(feats, K + 48)
+            win = spectral_ref.edge_window_end(lam64, K, 1e-4)
+            assert win < K + 47, f"{name}: the 1e-4 window above eigenvalue K-1 holds more than 48 eigenvalues"
+            k2 = max(win + 2, K + 3)
+            isolated = [lo for lo, hi in spectral_ref.eig_clusters(lam64[:k2], 1e-4) if lo == hi and lo < K]
+            for draws in range(1, 6):
+                dev = spectral_ref.cos_err(evec.numpy()[isolated], v64[isolated]).max() if isolated else 0.0
+                if dev <= 1e-5:
+                    break
+                print(f"[golden] eigs_{name}: reference draw {draws} is {dev:.1e} from the fp64 solution - re-drawing")
+                (odir / f"{name}.pth").unlink()
+                ref._extract_eig((0, str(fdir / f"{name}.pth")), K=K, images_root="", output_dir=str(odir),
+                                 image_color_lambda=0.0)
+                out = torch.load(odir / f"{name}.pth", map_location="cpu", weights_only=False)
+                ev, evec = out["eigenvalues"], out["eigenvectors"]
+            else:
+                raise RuntimeError(f"{name}: 5 reference draws, all further than 1e-5 from the fp64 solution")
         np.savez_compressed(GOLDEN / f"eigs_{name}.npz", kind=kind, n=n, d=d, seed=seed, hw=np.array(hw), K=K,
                             shape=np.array(shape), patch=patch,
                             eigenvalues=ev.numpy().astype(np.float32), eigenvectors=evec.numpy(),
-                            eigenvalues_dtype=str(ev.dtype))
-        print(f"[golden] eigs_{name}: lambda={ev.numpy()[:6]}")
+                            eigenvalues_dtype=str(ev.dtype),
+                            # fp64 dense solution of the same problem, K + E pairs reaching lambda[K-1] + 1e-4: lets
+                            # tests/util.check_eigs decide a cluster of near-equal eigenvalues that straddles K - 1
+                            eigenvalues_ext=lam64[:k2], eigenvectors_ext=v64[:k2].astype(np.float32),
+                            reference_draws=draws, reference_vs_f64_cos_err=float(dev))
+        print(f"[golden] eigs_{name}: lambda={ev.numpy()[:6]} ({draws} draw(s), {dev:.1e} from fp64; "
+              f"{k2 - K} extra fp64 pairs, 1e-4 window above K-1 ends at {win})")
 
 
 # --------------------------------------------------------------------------- feature cases
@@ -387,13 +412,16 @@ def main():
     GOLDEN.mkdir(parents=True, exist_ok=True)
     torch.set_grad_enabled(False)  # extract.py:838
     os.environ.setdefault("OMP_NUM_THREADS", "8")
-    check_vit_against_hf()  # before the stubs: transformers probes for a real torchvision
+    if not sys.argv[1:]:
+        check_vit_against_hf()  # before the stubs: transformers probes for a real torchvision
     ref = _import_reference()
-    make_index_probe(ref)
-    make_feature_goldens(ref)
-    make_eig_goldens(ref)
-    make_single_region_golden(ref)
-    make_mode_goldens(ref)
+    only = set(sys.argv[1:])  # e.g. `python oracle/make_golden.py eigs modes`; nothing = everything
+    steps = {"probe": make_index_probe, "features": make_feature_goldens, "eigs": make_eig_goldens,
+             "single_region": make_single_region_golden, "modes": make_mode_goldens}
+    assert only <= set(steps), f"unknown step(s) {only - set(steps)}; known: {sorted(steps)}"
+    for name, fn in steps.items():
+        if not only or name in only:
+            fn(ref)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 import dss_amd  # noqa: F401
 from dss_amd import hip, spectral, synthetic
 from oracle import spectral_ref, vit_ref
-from tests.util import build_w64, check_eigs, d_orthonormality, golden_case
+from tests.util import build_w64, check_eigs, d_orthonormality, golden_case, golden_ext
 
 pytestmark = pytest.mark.gpu
 HERE = Path(__file__).resolve().parent
@@ -294,11 +294,12 @@ EIG_FILES = sorted(glob.glob(str(HERE / "golden" / "eigs_*.npz")))
 @pytest.mark.parametrize("path", EIG_FILES, ids=lambda p: p.split("eigs_")[-1][:-4])
 def test_eigs_match_reference_goldens(path, w_dtype, monkeypatch):
     monkeypatch.setenv("DSS_W_DTYPE", w_dtype)
-    feats, K, ref_lam, ref_vec, _ = golden_case(path)
+    feats, K, ref_lam, ref_vec, g = golden_case(path)
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
     assert info.item() > 0
     assert vec.dtype == torch.float32 and tuple(vec.shape) == (1, K, feats.shape[0]) and tuple(ev.shape) == (1, K)
-    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), ref_vec, ref_lam, what=path)
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), ref_vec, ref_lam, what=path, d=build_w64(feats)[1],
+               ext=golden_ext(g))
     if feats.shape[0] <= 1600:
         _, d = build_w64(feats)
         assert d_orthonormality(vec[0].cpu().numpy(), d=d) < 1e-4  # v^T D v = 1 like ARPACK with M=D
@@ -332,17 +333,19 @@ def test_eigs_batch_against_oracle(mode):
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), K, affinity_mode=mode)
     assert (info > 0).all()
     for i in range(b):
-        lam, v = spectral_ref.ref_laplacian_eigs(torch.from_numpy(feats[i])[None], K)
-        check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"img{i}")
+        lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(torch.from_numpy(feats[i])[None], K)
+        check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"img{i}",
+                   d=build_w64(feats[i])[1], ext=ext)
 
 
 @pytest.mark.parametrize("n,d,K", [(16, 32, 5), (12, 32, 3), (70, 64, 1), (70, 64, 2), (196, 384, 20), (333, 96, 7)])
 def test_eigs_edge_shapes_against_fp64(n, d, K):
     feats = synthetic.synthetic_features("random", n, d, 4000 + n + K)
-    lam64, v64 = spectral_ref.dense_f64_eigs(feats, K)
+    lam64, v64 = spectral_ref.dense_f64_eigs(feats, min(K + 8, n))
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
     assert info.item() > 0
-    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v64, lam64, what=f"n{n}K{K}")
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v64[:K], lam64[:K], what=f"n{n}K{K}", d=build_w64(feats)[1],
+               ext=(lam64, v64))
 
 
 def test_eigs_rejects_bad_arguments_and_reports_nonconvergence():
@@ -357,7 +360,8 @@ def test_eigs_rejects_bad_arguments_and_reports_nonconvergence():
     ev, vec, info = spectral.laplacian_eigs_from_features(feats, 5, max_restarts=1)
     assert info.item() > 0
     g = np.load(HERE / "golden" / "eigs_g2_random_900.npz")
-    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), g["eigenvectors"], g["eigenvalues"], what="retry")
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), g["eigenvectors"], g["eigenvalues"], what="retry",
+               ext=golden_ext(g))
     w = hip.affinity(hip.normalize_rows(feats))
     with pytest.raises(hip.HipLibraryError):
         hip.laplacian_eigs(w, 900, 40, ncv=30)  # Krylov dimension too small for K

@@ -9,7 +9,7 @@ import torch
 import dss_amd  # noqa: F401
 from dss_amd import synthetic
 from oracle import spectral_ref, vit_ref
-from tests.util import check_eigs, golden_case, build_w64, d_orthonormality
+from tests.util import check_eigs, golden_case, golden_ext, build_w64, d_orthonormality
 
 EIG_FILES = sorted(glob.glob(str(__import__("pathlib").Path(__file__).parent / "golden" / "eigs_*.npz")))
 
@@ -23,7 +23,15 @@ def test_oracle_eigs_match_reference_goldens(path):
     feats, K, ref_lam, ref_vec, g = golden_case(path)
     lam, vec = spectral_ref.ref_laplacian_eigs(torch.from_numpy(feats)[None], K)
     assert vec.dtype == torch.float32 and tuple(vec.shape) == (K, feats.shape[0])
-    check_eigs(vec.numpy(), lam.numpy(), ref_vec, ref_lam, what=path)
+    check_eigs(vec.numpy(), lam.numpy(), ref_vec, ref_lam, what=path, d=build_w64(feats)[1], ext=golden_ext(g))
+    # the oracle call the end-to-end parity checks use: validated reference draw + fp64 extra pairs
+    lam2, vec2, ext, draws = spectral_ref.ref_laplacian_eigs_ext(torch.from_numpy(feats)[None], K)
+    x_lam, x_vec = golden_ext(g)
+    assert 1 <= draws <= 4 and ext[1].shape[0] >= K + 3 and ext[1].shape[0] == x_vec.shape[0]
+    assert spectral_ref.edge_window_end(ext[0], K, 1e-4) < ext[1].shape[0] - 1
+    np.testing.assert_allclose(ext[0], x_lam, rtol=0, atol=1e-9)
+    check_eigs(vec2.numpy(), lam2.numpy(), ref_vec, ref_lam, what=path + " (ext)", d=build_w64(feats)[1], ext=ext)
+    assert int(g["reference_draws"]) >= 1 and float(g["reference_vs_f64_cos_err"]) <= 1e-5
 
 
 def test_golden_conventions():
