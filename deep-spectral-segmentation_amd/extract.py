@@ -43,7 +43,7 @@ else:
     from . import spectral
     from .distributed import init_process_group, rank_world, local_device
 
-_DTYPES = {"float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+_DTYPES = {"float16": torch.float16, "fp16": torch.float16, "f16": torch.float16, "half": torch.float16,
            "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
 
 
@@ -97,11 +97,22 @@ def _barrier():
 
 
 def _make_output_dir_all_ranks(output_dir: str):
-    """Rank 0 runs the reference's (possibly interactive) non-empty check BEFORE any rank writes; the others wait."""
+    """Rank 0 runs the reference's (possibly interactive) non-empty check BEFORE any rank writes; the others wait for
+    its DECISION, not just for a barrier: if rank 0 declines the prompt (``sys.exit``) or fails, every rank leaves."""
     rank, _ = rank_world()
+    err = None
     if rank == 0:
-        utils.make_output_dir(output_dir)
-    _barrier()
+        try:
+            utils.make_output_dir(output_dir)
+        except BaseException as e:  # SystemExit from the prompt included
+            err = e
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        verdict = [None if err is None else f"{type(err).__name__}: {err}"]
+        torch.distributed.broadcast_object_list(verdict, src=0)
+        if verdict[0] is not None and rank != 0:
+            raise SystemExit(f"[dss] rank 0 did not open {output_dir} ({verdict[0]}): rank {rank} stops too")
+    if err is not None:
+        raise err
     if rank != 0:
         utils.make_output_dir(output_dir, check_if_empty=False)
 
@@ -209,9 +220,15 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
                    device: torch.device, saver: Optional["_AsyncSaver"] = None, problem: str = "laplacian",
                    upsample=None):
     feats = torch.stack([f for _, f in items]).to(device, non_blocking=True)
-    ev, vec, _ = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
-                                                       threshold_at_zero=threshold_at_zero, problem=problem,
-                                                       upsample=upsample)
+    # strict=False: the reference never aborts a run over one image (bare except -> second solve, extract.py:228-229).
+    # laplacian_eigs_from_features re-solves a starved image with a larger Krylov space and, failing that, densely;
+    # anything still flagged is saved as it is and reported here.
+    ev, vec, info = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
+                                                          threshold_at_zero=threshold_at_zero, problem=problem,
+                                                          upsample=upsample, strict=False)
+    bad = (info <= 0).nonzero().flatten().tolist()
+    if bad:
+        print(f"[dss] WARNING: eigensolver did not converge for {[items[j][0] for j in bad]} (saved as is)")
     ev, vec = ev.cpu(), vec.cpu()
     for j, (output_file, _) in enumerate(items):
         # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32; the 'affinity'
@@ -269,6 +286,9 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         return data_dict, feats
 
     pending: Dict[Tuple, List[Tuple[str, torch.Tensor]]] = {}
+    problems: Dict[Tuple, str] = {}
+    bs = max(1, int(batch_size))
+    n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
     saver = _AsyncSaver()
     with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
         for data_dict, feats in _bounded_map(pool, load, mine, 4 * max(1, int(batch_size))):
@@ -283,10 +303,15 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
             key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
             pending.setdefault(key, []).append((output_file, feats))
-            if len(pending[key]) >= max(1, int(batch_size)):
-                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problem, key[1])
+            problems[key] = problem
+            n_pending += 1
+            if len(pending[key]) < bs and n_pending >= max_pending:
+                key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
+            if len(pending[key]) >= bs or n_pending >= max_pending:
+                n_pending -= len(pending[key])
+                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1])
     for key in list(pending):
-        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problem, key[1])
+        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1])
     saver.close()
     _barrier()
 

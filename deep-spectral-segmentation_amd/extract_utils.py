@@ -55,8 +55,12 @@ class ImagesDataset:
         path = self.filenames[index]
         full_path = Path(path) if self.root is None else self.root / path
         assert full_path.is_file(), f"Not a file: {full_path}"
+        from PIL import ImageOps
+
         with Image.open(full_path) as im:
-            image = torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8))
+            # cv2.imread (the reference's decoder, extract_utils.py:30) applies the EXIF orientation; PIL does not
+            # unless asked to
+            image = torch.from_numpy(np.array(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8))
         if self.transform is not None:
             image = self.transform(image)
         return image, path, index

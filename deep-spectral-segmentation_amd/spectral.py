@@ -36,6 +36,58 @@ def _reference_order(problem: str, ev: torch.Tensor, vec: torch.Tensor):
     return ev, vec
 
 
+MAX_LANCZOS_K = 62   # dss_symmetric_eigs: Krylov dimension <= 64 and ncv >= K + 2 (csrc/eigs_core.h EIGS_MAX_NCV)
+
+
+@torch.no_grad()
+def dense_eigs(feats: torch.Tensor, K: int, normalize: bool, threshold_at_zero: bool, problem: str):
+    """Exceptional path, never the hot one: the same eigenproblems solved densely in fp64 on the GPU
+    (``torch.linalg.eigh``, rocSOLVER) image by image.  Used for (a) an image whose Lanczos run exhausted even the
+    enlarged restart budget - the reference reacts to an ARPACK failure with a second solve too (``which='SM'``,
+    extract.py:228-229) and ALWAYS writes a file - and (b) ``K > 62``, beyond the Krylov space of the HIP kernel (the
+    reference accepts any ``K < N``).  Returns pairs in the kernel's ranking order, sign rule applied."""
+    evs, vecs = [], []
+    for f in feats:
+        x = f.double()
+        if normalize:
+            x = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        w = x @ x.T
+        if threshold_at_zero:
+            w = w.clamp_min(0)
+        if problem in ("affinity", "affinity_svd"):
+            th, u = torch.linalg.eigh(w)
+            order = th.abs().argsort(descending=True)[:K]
+            ev, v = th[order], u[:, order].T
+        else:
+            d = w.sum(1)
+            d = torch.where(d < 1e-12, torch.ones_like(d), d)
+            if problem == "laplacian":
+                dis = d.rsqrt()
+                th, u = torch.linalg.eigh(w * dis[:, None] * dis[None, :])
+                ev, v = (1.0 - th).flip(0)[:K], (u * dis[:, None]).T.flip(0)[:K]
+            else:
+                lam, u = torch.linalg.eigh(torch.diag(d) - w)
+                ev, v = lam[:K], u[:, :K].T
+        evs.append(ev.float())
+        vecs.append(v.float().contiguous())
+    ev, vec = torch.stack(evs), torch.stack(vecs).contiguous()
+    hip.sign_rule_(vec)
+    return ev, vec
+
+
+def reference_scale(problem: str, wmax: torch.Tensor, ev: torch.Tensor, vec: torch.Tensor):
+    """Outputs of the eigenproblem on W -> outputs of the reference's problem on ``W / wmax`` (extract.py:194), per image.
+    ``laplacian``: ``(D - W) v = lam D v`` is scale invariant, but ARPACK normalises ``v^T (D / wmax) v = 1``: vectors
+    grow by ``sqrt(wmax)``.  ``laplacian_unnormalized``: the eigenvalues of ``(D - W) / wmax`` are ``lam / wmax``, unit
+    eigenvectors unchanged.  An all-zero feature matrix (wmax = 0: NaN in the reference) is left unscaled."""
+    wmax = torch.where(wmax > 0, wmax, torch.ones_like(wmax)).to(ev.dtype)
+    if problem == "laplacian":
+        return ev, vec * wmax.sqrt()[:, None, None]
+    if problem == "laplacian_unnormalized":
+        return ev / wmax[:, None], vec
+    return ev, vec
+
+
 @torch.no_grad()
 def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
                                  threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
@@ -86,6 +138,7 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         normalize, n = False, hl * wl  # extract.py normalises BEFORE the resize and not again after it
     if not K < n:
         raise ValueError(f"need K < N (K={K}, N={n})")
+    dense_all = K > MAX_LANCZOS_K and n > K + 2   # tiny N: the Krylov space is the whole space, the kernel handles it
     raw = problem.startswith("_raw_")  # internal: keep the solver's ranking order (used by the retry path)
     if raw:
         problem = problem[5:]
@@ -93,6 +146,13 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         raise ValueError(f"unknown problem {problem!r}")
     if problem == "affinity_svd":
         threshold_at_zero = False  # the singular vectors of F are the eigenvectors of the UN-thresholded F F^T
+    # extract.py:194 `W_feat = W_feat / W_feat.max()` (Laplacian branches only).  The kernels work on the unscaled W; the
+    # division is put back on the outputs (reference_scale).  W.max() is max_i |f_i|^2 - Cauchy-Schwarz bounds every
+    # entry by it and the diagonal attains it - which is 1 for normalised rows: only un-normalised or upsampled
+    # (interpolated, not re-normalised) features need it.
+    wmax = None
+    if problem in ("laplacian", "laplacian_unnormalized") and not normalize and not raw:
+        wmax = feats.square().sum(-1).amax(-1)
     # W as 16-bit fixed point (half the bytes of the solver's only HBM stream) whenever the problem allows it: the
     # normalised Laplacian is invariant to the scale of W, and normalised + thresholded similarities lie in [0, 1]
     # (after an upsample the rows are interpolated, not re-normalised: |w| <= 1 still holds, but keep f32 there).
@@ -102,7 +162,11 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     per_image = hip.affinity_elems(n) * (2 if w_u16 else 4) + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
     evals, evecs, infos = [], [], []
-    for s in range(0, b, chunk):
+    if dense_all:
+        print(f"[dss] K={K} > {MAX_LANCZOS_K}: beyond the Krylov space of the Lanczos kernel - dense fp64 solve per image")
+        ev, vec = dense_eigs(feats, K, normalize, threshold_at_zero, problem)
+        evals.append(ev), evecs.append(vec), infos.append(torch.ones(b, dtype=torch.int32, device=feats.device))
+    for s in range(0, 0 if dense_all else b, chunk):
         f = feats[s:s + chunk].contiguous()
         if affinity_mode == "fp32" or d % 32 != 0:  # exact fp32 MFMA (bitwise an fmaf chain), MFMA-bound
             if normalize:
@@ -127,6 +191,13 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
             tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60), max_bytes=max_bytes,
             strict=False, affinity_mode=affinity_mode, retry=False, problem="_raw_" + problem, upsample=None)
         ev[bad], vec[bad], info[bad] = ev2, vec2, info2
+        still = (info <= 0).nonzero().flatten()
+        if still.numel():   # last resort, like the reference's second eigsh call: it always produces an answer
+            print(f"[dss] {still.numel()} image(s) still unconverged: dense fp64 solve for them")
+            ev[still], vec[still] = dense_eigs(feats[still], K, normalize, threshold_at_zero, problem)
+            info[still] = info[still].abs().clamp_min(1)
+    if wmax is not None:
+        ev, vec = reference_scale(problem, wmax, ev, vec)
     if not raw:
         ev, vec = _reference_order(problem, ev, vec)
     if strict:

@@ -361,6 +361,12 @@ MODE_CASES = [  # name, kind, n, d, seed, hw, K, kwargs for the reference's _ext
     # feature upsampling (extract.py:179-188): P=16 features on an 8-pixel grid -> 2x bilinear, N_lr = 4 N
     ("upsample8_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="laplacian", image_downsample_factor=8)),
     ("upsample8_blobs_23x31", "blobs", 713, 384, 401, (23, 31), 4, dict(which_matrix="laplacian", image_downsample_factor=8)),
+    # `W_feat / W_feat.max()` (extract.py:194) matters when the rows are not unit vectors: magnitudes, not just cosines
+    ("nonorm_blobs_196", "blobs", 196, 384, 102, (14, 14), 5, dict(which_matrix="laplacian", normalize=False)),
+    ("nonorm_lapnorm_false_blobs_196", "blobs", 196, 384, 102, (14, 14), 5,
+     dict(which_matrix="laplacian", lapnorm=False, normalize=False)),
+    ("upsample8_lapnorm_false_blobs_196", "blobs", 196, 384, 102, (14, 14), 4,
+     dict(which_matrix="laplacian", lapnorm=False, image_downsample_factor=8)),
 ]
 
 

@@ -417,10 +417,14 @@ def test_other_branches_match_reference_goldens(path):
         up = ((hp, wp), (hp * f, wp * f))
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K, problem=problem,
                                                           threshold_at_zero=kw.get("threshold_at_zero", True),
-                                                          upsample=up)
+                                                          normalize=kw.get("normalize", True), upsample=up)
     assert info.item() > 0
     lam, v = ev[0].cpu().numpy().astype(np.float64), vec[0].cpu().numpy()
     ref_lam, ref_v = np.asarray(g["eigenvalues"], np.float64), g["eigenvectors"]
+    # MAGNITUDES, not just directions: the reference divides W by W.max() (extract.py:194), which rescales the
+    # D-orthonormal vectors (lapnorm) or the eigenvalues (lapnorm=False) whenever the feature rows are not unit vectors
+    ratio = np.linalg.norm(v, axis=1) / np.linalg.norm(ref_v, axis=1)
+    assert np.abs(ratio - 1).max() < 2e-3, (path, ratio)
     scale = max(1.0, np.abs(ref_lam).max())
     tol = dict(lam_tol=2e-5 * scale, gap_tol=1e-4 * scale)
     if problem == "affinity":        # values ascending, vectors descending: flip the vectors to a common order
@@ -429,3 +433,58 @@ def test_other_branches_match_reference_goldens(path):
         check_eigs(v[::-1], lam[::-1], ref_v[::-1], ref_lam[::-1], what=path, **tol)
     else:
         check_eigs(v, lam, ref_v, ref_lam, what=path, **tol)
+
+
+# ----------------------------------------------------------------------------- exceptional dense path
+@pytest.mark.parametrize("path", [p for p in EIG_FILES if "3600" not in p and "1600" not in p],
+                         ids=lambda p: p.split("eigs_")[-1][:-4])
+def test_dense_fallback_matches_reference_goldens(path):
+    """spectral.dense_eigs - the per-image last resort behind the Lanczos kernel (the reference's second eigsh call,
+    extract.py:228-229) and the K > 62 path - against the reference's own outputs, same bar."""
+    feats, K, ref_lam, ref_vec, g = golden_case(path)
+    ev, vec = spectral.dense_eigs(torch.from_numpy(feats)[None].to(DEV), K, True, True, "laplacian")
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), ref_vec, ref_lam, what=path, d=build_w64(feats)[1],
+               ext=golden_ext(g))
+    for k in range(K):
+        assert not (0.5 < (vec[0, k] > 0).float().mean().item() < 1.0)
+
+
+def test_k_beyond_the_krylov_space_takes_the_dense_path(capsys):
+    """The reference accepts any K < N; the Lanczos kernel holds at most 64 basis vectors (K <= 62)."""
+    n, d, K = 196, 384, 70
+    feats = synthetic.synthetic_features("blobs", n, d, 102, (14, 14))
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K)
+    assert "dense fp64 solve" in capsys.readouterr().out and info.item() > 0 and tuple(vec.shape) == (1, K, n)
+    lam64, v64 = spectral_ref.dense_f64_eigs(feats, K + 8)
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v64[:K], lam64[:K], what="K70", d=build_w64(feats)[1],
+               ext=(lam64, v64))
+    # the same K through the other branches keeps their conventions (ordering quirks, schema)
+    for problem in ("affinity", "affinity_svd", "laplacian_unnormalized"):
+        e, v, i = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K, problem=problem)
+        e5, v5, _ = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), 5, problem=problem)
+        if problem == "affinity":      # ascending values: the 5 largest are the last 5; vectors are in descending order
+            assert torch.allclose(e[0, -5:], e5[0], rtol=1e-4) and (1 - torch.nn.functional.cosine_similarity(
+                v[0, :5], v5[0], dim=-1).abs()).max().item() < 1e-4
+        else:
+            assert torch.allclose(e[0, :5], e5[0], rtol=1e-4, atol=1e-4)
+            assert (1 - torch.nn.functional.cosine_similarity(v[0, :4], v5[0, :4], dim=-1).abs()).max().item() < 1e-4
+
+
+def test_starved_image_falls_back_per_image_without_aborting_the_batch(capsys, monkeypatch):
+    """one unconverged image must not take the batch (or the other ranks) down.  With the restart budget
+    forced to 1 and the retry's Krylov space capped the same way, the dense solve answers for that image only."""
+    feats = np.stack([synthetic.synthetic_features("random", 900, 384, 201, (30, 30)),
+                      synthetic.synthetic_features("blobs", 900, 384, 202, (30, 30))])
+    real = hip.laplacian_eigs
+
+    def starved(w, n, k, ncv=0, tol=0.0, max_restarts=0, **kw):   # every Lanczos launch gets a budget of one restart
+        return real(w, n, k, ncv=ncv, tol=tol, max_restarts=1, **kw)
+
+    monkeypatch.setattr(hip, "laplacian_eigs", starved)
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), 5, strict=True)
+    out = capsys.readouterr().out
+    assert "dense fp64 solve for them" in out and (info > 0).all()
+    for i, name in enumerate(("g2_random_900", "g2_blobs_900")):
+        g = np.load(HERE / "golden" / f"eigs_{name}.npz")
+        check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), g["eigenvectors"], g["eigenvalues"], what=name,
+                   ext=golden_ext(g))

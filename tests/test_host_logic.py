@@ -186,3 +186,37 @@ def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp
         assert abs(new["kernels"][key]["hbm_bytes_per_launch"] - old["kernels"][key]["hbm_bytes_per_launch"]) < 1.0
         k = old["kernels"][key]
         assert abs((2 * k["fetch_size_kb"] + k["write_size_kb"]) * 1024 - k["hbm_bytes_per_launch"]) < 2048
+
+
+def test_reference_scale_puts_the_division_by_wmax_back():
+    """extract.py:194 on the outputs: eigenvectors * sqrt(wmax) for the normalised Laplacian, eigenvalues / wmax for
+    lapnorm=False, nothing for the affinity branches; a zero matrix is left alone."""
+    import torch
+    from dss_amd.spectral import reference_scale
+
+    ev, vec = torch.tensor([[0.0, 2.0], [0.0, 6.0]]), torch.ones(2, 2, 3)
+    wmax = torch.tensor([4.0, 0.0])
+    e, v = reference_scale("laplacian", wmax, ev, vec)
+    assert torch.equal(e, ev) and torch.equal(v[0], 2 * vec[0]) and torch.equal(v[1], vec[1])
+    e, v = reference_scale("laplacian_unnormalized", wmax, ev, vec)
+    assert torch.equal(e, torch.tensor([[0.0, 0.5], [0.0, 6.0]])) and torch.equal(v, vec)
+    e, v = reference_scale("affinity", wmax, ev, vec)
+    assert torch.equal(e, ev) and torch.equal(v, vec)
+
+
+def test_dataset_applies_exif_orientation_like_cv2(tmp_path):
+    """cv2.imread (reference extract_utils.py:30) honours the EXIF orientation tag; so must the PIL decode."""
+    import numpy as np
+    from PIL import Image
+
+    from dss_amd import extract_utils
+
+    arr = (np.arange(20 * 30 * 3) % 251).astype(np.uint8).reshape(20, 30, 3)
+    exif = Image.Exif()
+    exif[0x0112] = 6   # "rotate 90 CW to display"
+    Image.fromarray(arr).save(tmp_path / "rot.png", exif=exif)
+    Image.fromarray(arr).save(tmp_path / "plain.png")
+    ds = extract_utils.ImagesDataset(["rot.png", "plain.png"], str(tmp_path))
+    plain, rot = ds[0][0], ds[1][0]
+    assert tuple(plain.shape) == (20, 30, 3) and tuple(rot.shape) == (30, 20, 3)
+    assert np.array_equal(rot.numpy(), np.rot90(arr, k=-1))
