@@ -477,8 +477,8 @@ def test_starved_image_falls_back_per_image_without_aborting_the_batch(capsys, m
                       synthetic.synthetic_features("blobs", 900, 384, 202, (30, 30))])
     real = hip.laplacian_eigs
 
-    def starved(w, n, k, ncv=0, tol=0.0, max_restarts=0, **kw):   # every Lanczos launch gets a budget of one restart
-        return real(w, n, k, ncv=ncv, tol=tol, max_restarts=1, **kw)
+    def starved(w, n, k, ncv=0, tol=0.0, max_restarts=0, **kw):   # every Lanczos launch: 12 basis vectors, one restart
+        return real(w, n, k, ncv=12, tol=tol, max_restarts=1, **kw)
 
     monkeypatch.setattr(hip, "laplacian_eigs", starved)
     ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats).to(DEV), 5, strict=True)
