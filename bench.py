@@ -2,17 +2,23 @@
 """bench.py - images/sec of the extract hot path (features + eigs) on MI355X, with the kernel roofline
 and a CPU baseline (the oracle, i.e. the reference's numpy/scipy/torch-CPU path) timed beside it.
 
-    python bench.py [--gpus N --steps K --warmup W]          # N=1 directly; N>1 under torch.distributed.run
+    python bench.py [--gpus N --steps K --warmup W]
+
+``--gpus N`` with N > 1 launches itself as N ranks (``python -m torch.distributed.run --nproc-per-node N``, one process
+per GPU over RCCL) unless it already runs under such a launcher (WORLD_SIZE set); the line reports ``ranks_seen``.
 
 Workload (BASELINE.json configs[1]): dino_vits16, 480x480 synthetic VOC-shaped images, K=5.
-One STEP = one batch of ``--batch`` images (default 7 ViT forwards of 290 = 2030 at the headline config) already
-resident in HBM as uint8 HWC:
-transform+crop+im2col -> ViT (HIP LayerNorm/attention/K-resident Linear kernels, hipBLASLt for the other GEMMs) -> K features -> normalise ->
-affinity -> Lanczos eigenpairs -> [K, N] eigenvectors.  One ``B=1`` result per image, like the reference.
-Every rank streams its own results to pinned host memory asynchronously, step by step (that is where the CLI
-writes the per-image .pth files from).  Multi-GPU: every rank runs the same number of steps on its own images
-(weak scaling, no collective on the data path) and rank 0 gathers all eigenvectors once at the end, device to
-device (the single RCCL gather over xGMI) - all inside the timed region.
+One STEP = one batch of ``--batch`` images (default 7 ViT forwards of 290 = 2030 at the headline config):
+H2D of the uint8 HWC images (pinned host memory -> HBM on a copy stream, double buffered: the batch of step s+1 travels
+while step s computes - INSIDE the timed region) -> transform+crop+im2col -> ViT (HIP
+LayerNorm/attention/K-resident Linear kernels, hipBLASLt for the other GEMMs) -> K features -> normalise -> affinity
+-> Lanczos eigenpairs -> [K, N] eigenvectors -> D2H of every rank's own results to pinned host memory (where the CLI
+writes the per-image .pth files from).  One ``B=1`` result per image, like the reference.
+Multi-GPU: no collective on the data path; rank 0 collects all results once at the end (sizes first, then one flat
+payload per rank, point to point over xGMI) - inside the timed region.
+  * default: every rank runs ``--steps`` steps on its own images: ``"scaling": "weak"``;
+  * ``--dataset D`` (BASELINE configs[3]: 10000): a fixed set of D images, item i on rank i % world, per-rank steps
+    sized from the shard: ``"scaling": "strong"``.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -31,7 +37,7 @@ import torch
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 import dss_amd  # noqa: E402,F401
-from dss_amd import distributed, hip, pipeline, synthetic  # noqa: E402
+from dss_amd import distributed, hip, pipeline, spectral, synthetic  # noqa: E402
 from dss_amd.vit import DinoViT  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -50,12 +56,23 @@ def parse():
     ap.add_argument("--vit-batch", type=int, default=0,
                     help="images per ViT forward (0 = near 256, sized so the token matrix fills whole waves of "
                          "workgroups: vit.wave_filling_batch; 290 for dino_vits16 at 480x480)")
+    ap.add_argument("--dataset", type=int, default=0,
+                    help="strong scaling: a fixed set of this many images sharded round-robin over the ranks "
+                         "(BASELINE.json configs[3]: 10000); --steps is then derived from the shard")
     ap.add_argument("--model", default="dino_vits16")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--K", type=int, default=5)
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16"])
+    ap.add_argument("--w-dtype", default="u16", choices=["u16", "f32"],
+                    help="storage of the affinity matrix the eigensolver streams: u16 = round(65535 w) fixed point "
+                         "(default; the arithmetic stays fp32), f32 = floats")
+    ap.add_argument("--companion-steps", type=int, default=2,
+                    help="N=1 only: after the main measurement, time this many steps with the OTHER --w-dtype and report "
+                         "them as value_w_<dtype> (0 = skip)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images of the same workload timed on the CPU oracle")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images generated per rank")
+    ap.add_argument("--resident", action="store_true",
+                    help="diagnostic: keep the images resident in HBM (no H2D in the timed region; NOT the reported mode)")
     ap.add_argument("--min-warmup-seconds", type=float, default=4.0,
                     help="keep running untimed warm-up steps (beyond --warmup) until this much wall time has passed: "
                          "the first GPU process on a fresh box runs ~20 %% slower until clocks/power have ramped")
@@ -72,11 +89,27 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks_if_needed(a):
+    """``python bench.py --gpus N`` on its own: re-execute under torch.distributed.run with N ranks on this node."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] --gpus {a.gpus} without a launcher: spawning {a.gpus} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 _OVERLAP = {}
 _STREAMS = {}
 
 
-def step(model, imgs, K, vit_batch, overlap=False, nstreams=1):
+def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
     """One pass of the hot path over one batch: features + eigs for every image."""
     if overlap:  # spectral stage of sub-batch i on a side stream under the ViT of sub-batch i+1
         key = (id(model), K, vit_batch)
@@ -98,9 +131,56 @@ def step(model, imgs, K, vit_batch, overlap=False, nstreams=1):
     else:
         ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
     k = torch.cat(ks) if len(ks) > 1 else ks[0]
-    from dss_amd import spectral
     # strict=False, retry=False: no device->host sync inside the step (convergence is checked once, after timing)
-    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False)
+    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype)
+
+
+class ImageFeeder:
+    """The u8 images of every step travel host -> HBM inside the timed region: a pinned host pool of ``n_distinct``
+    images, two device batches, a copy stream.  ``prefetch(s)`` enqueues the copies of step s (contiguous runs of the
+    pool, so the PCIe volume is the full batch, with no host-side assembly); ``get(s)`` makes the compute stream wait for
+    them; ``release(s)`` marks the batch free once the step's kernels have been enqueued."""
+
+    def __init__(self, host_pool: torch.Tensor, batch: int, dev, resident: bool = False):
+        self.pool, self.batch, self.n = host_pool, batch, host_pool.shape[0]
+        self.resident = resident
+        if resident:
+            self.dev_pool = host_pool.to(dev)
+            return
+        self.bufs = [torch.empty((batch, *host_pool.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [None, None]
+
+    def prefetch(self, s: int, count: int = 0):
+        if self.resident:
+            return
+        b = s & 1
+        count = count or self.batch
+        with torch.cuda.stream(self.stream):
+            if self.free[b] is not None:
+                self.stream.wait_event(self.free[b])
+            j, off = 0, (s * self.batch) % self.n
+            while j < count:
+                run = min(self.n - off, count - j)
+                self.bufs[b][j:j + run].copy_(self.pool[off:off + run], non_blocking=True)
+                j, off = j + run, (off + run) % self.n
+            self.ready[b].record(self.stream)
+
+    def get(self, s: int, count: int = 0):
+        count = count or self.batch
+        if self.resident:
+            idx = (torch.arange(count, device=self.dev_pool.device) + s * self.batch) % self.n
+            return self.dev_pool[idx]
+        torch.cuda.current_stream().wait_event(self.ready[s & 1])
+        return self.bufs[s & 1][:count]
+
+    def release(self, s: int):
+        if self.resident:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.free[s & 1] = ev
 
 
 def summarize_timers(timers, n_patches, dim, depth_attn):
@@ -206,88 +286,129 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol)
              "non_isolated_clusters_per_image": clusters})
 
 
+def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_step=0):
+    """The timed region for this rank: ``len(counts)`` steps (``counts[s]`` images each), H2D prefetched one step ahead,
+    every step's results streamed to pinned host memory, one collection on rank 0 at the end.  Returns
+    (elapsed seconds, host-enqueue seconds, info tensors, gathered (meta, payload) or None)."""
+    dev = model.device
+    width = a.K * n_patches + a.K
+    host_out = torch.empty((len(counts), max(counts), width), dtype=torch.float32, pin_memory=True)
+    copy_stream = torch.cuda.Stream(device=dev)
+    infos, metas, flats = [], [], []
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feeder.prefetch(first_step, counts[0])
+    base = 0
+    for s, cnt in enumerate(counts):
+        if s + 1 < len(counts):
+            feeder.prefetch(first_step + s + 1, counts[s + 1])
+        imgs = feeder.get(first_step + s, cnt)
+        ev, vec, info = step(model, imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
+        feeder.release(first_step + s)
+        ids = (torch.arange(cnt, device=dev, dtype=torch.int64) + base) * world + rank   # global round-robin item ids
+        base += cnt
+        meta, flat = distributed.pack_records(ids, ev, vec)
+        infos.append(info), metas.append(meta), flats.append(flat)
+        # every rank streams ITS OWN [K, N] results to pinned host memory while the next step computes
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done)
+            host_out[s, :cnt].copy_(flat.view(cnt, width), non_blocking=True)
+    host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
+    # the ONE collection of the run: sizes, then every rank's flat payload point to point to rank 0 (RCCL over xGMI)
+    gathered = distributed.gather_records_to_root(torch.cat(metas), torch.cat(flats))
+    copy_stream.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tdev = dev if torch.distributed.get_backend() != "gloo" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, host_enqueue_s, infos, gathered
+
+
 def main():
     a = parse()
+    spawn_ranks_if_needed(a)
     rank, world = distributed.init_process_group()
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                         f"(or run `python bench.py --gpus {a.gpus}` alone: it spawns its own ranks)")
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1 and backend != "nccl" and not os.environ.get("DSS_DIST_BACKEND"):
+        raise SystemExit(f"[bench] multi-GPU runs must use the nccl (= RCCL) backend, got {backend}")
     dev = distributed.local_device()
+    ranks_seen = [(rank, dev.index)]
+    if world > 1:
+        seen = [None] * world
+        torch.distributed.all_gather_object(seen, (rank, dev.index))
+        ranks_seen = sorted(seen)
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu)
     n_patches = (a.size // patch) ** 2
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
         from dss_amd.vit import wave_filling_batch
         rows = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
         target = min(256, max(8, round(256 * 901 / (n_patches + 1))))   # at most the token count of the headline config
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
     if a.batch <= 0:
-        # the eigensolver runs one 1024-thread workgroup per image, one per CU: pick the number of ViT forwards per
-        # step (4..8) whose image count best fills whole waves of CUs (290 x 7 = 2030 = 7.93 x 256)
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        # the eigensolver runs one workgroup per image: pick the number of ViT forwards per step (4..8) whose image
+        # count best fills whole waves of CUs (290 x 7 = 2030 = 7.93 x 256)
         fill = lambda m: (m * a.vit_batch / ncu) / math.ceil(m * a.vit_batch / ncu)
         a.batch = max(range(4, 9), key=lambda m: (round(fill(m), 3), -m)) * a.vit_batch
+    if a.dataset > 0:   # strong scaling: this rank's shard of a fixed set, in equal steps of at most the default batch
+        shard = len(distributed.shard_indices(a.dataset, rank, world))
+        n_steps = max(1, math.ceil(shard / a.batch))
+        per = math.ceil(shard / n_steps)
+        counts = [min(per, shard - i * per) for i in range(n_steps)]
+        counts = [c for c in counts if c > 0]
+        a.batch = max(counts)
+    else:
+        counts = [a.batch] * a.steps
 
-    # synthetic images, resident in HBM before the timed region (rank r owns global indices r, r+world, ...)
-    n_distinct = min(a.distinct, a.batch * (a.steps + a.warmup))
-    host = np.stack([synthetic.synthetic_image(rank + world * i, a.size, a.size) for i in range(n_distinct)])
-    pool = torch.from_numpy(host).to(dev)
-
-    def batch_for(s):
-        idx = (torch.arange(a.batch, device=dev) + s * a.batch) % n_distinct
-        return pool[idx]
+    # synthetic images in PINNED HOST memory (rank r owns global indices r, r+world, ...)
+    n_distinct = min(a.distinct, a.batch * (len(counts) + a.warmup))
+    host = torch.from_numpy(np.stack([synthetic.synthetic_image(rank + world * i, a.size, a.size)
+                                      for i in range(n_distinct)])).pin_memory()
+    feeder = ImageFeeder(host, a.batch, dev, resident=a.resident)
 
     from dss_amd.vit import setup_gemm_tuning
     setup_gemm_tuning(tune_new_shapes=True)   # warm-up may pick GEMM solutions for shapes missing from the shipped table
     t_warm = time.perf_counter()
     n_warm = 0
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
-        step(model, batch_for(n_warm % max(1, a.warmup)), a.K, a.vit_batch, a.overlap, a.vit_streams)
+        feeder.prefetch(n_warm)
+        step(model, feeder.get(n_warm), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+        feeder.release(n_warm)
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
-    results, packed_dev = [], []
-    width = a.K * n_patches + a.K + 1
-    host_out = torch.empty((a.steps, a.batch, width), dtype=torch.float32, pin_memory=True)  # this rank's results
-    copy_stream = torch.cuda.Stream(device=dev)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        ev, vec, info = step(model, batch_for(a.warmup + s), a.K, a.vit_batch, a.overlap, a.vit_streams)
-        ids = (torch.arange(a.batch, device=dev) + s * a.batch) * world + rank   # global round-robin item ids
-        packed = distributed.pack_results(ids, ev, vec)
-        results.append(info)
-        packed_dev.append(packed)
-        # every rank streams ITS OWN [K, N] results to pinned host memory while the next step computes
-        done = torch.cuda.Event()
-        done.record()
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(done)
-            host_out[s].copy_(packed, non_blocking=True)
-    host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
-    # the ONE collective of the run: gather every rank's packed rows on rank 0 (RCCL over xGMI when world > 1)
-    gathered = distributed.gather_to_root(torch.cat(packed_dev), a.steps * a.batch * world)
-    copy_stream.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if gathered is not None:
-        assert gathered.shape[0] == a.steps * a.batch * world
+    elapsed, host_enqueue_s, infos, gathered = run_steps(model, feeder, counts, a, rank, world, n_patches, a.w_dtype,
+                                                         first_step=n_warm)
     timers, hip.TIMERS = hip.TIMERS, None
+    n_images = sum(counts)
     if world > 1:
-        tdev = dev if torch.distributed.get_backend() != "gloo" else torch.device("cpu")
-        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tot = torch.tensor([n_images], device=dev, dtype=torch.int64)
+        torch.distributed.all_reduce(tot)
+        n_images = int(tot.item())
+    if gathered is not None:
+        assert gathered[0].shape[0] == n_images, (gathered[0].shape, n_images)
+        ids = gathered[0][:, 0]
+        assert ids.dtype == torch.int64 and bool((ids[1:] > ids[:-1]).all())   # every item exactly once, ordered
 
-    info_all = torch.cat(results)
+    info_all = torch.cat(infos)
     n_unconverged = int((info_all <= 0).sum().item())
     if rank == 0:
         kern = summarize_timers(timers, n_patches, dim, depth)
@@ -297,22 +418,44 @@ def main():
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"], "traffic": traffic[0] if traffic else None,
                     "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE)*1024", "traffic_source": traffic[1] if traffic else None}
+        steps_out = len(counts)
         out = {
             "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
-            "value": round(a.steps * a.batch * world / elapsed, 2), "unit": "images/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "warmup_steps_run": n_warm,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(n_images / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": steps_out, "warmup": a.warmup, "warmup_steps_run": n_warm,
+            "ms_per_step": round(elapsed / steps_out * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if a.dataset > 0 else "weak",
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": f"{a.model} {a.size}x{a.size} K={a.K}, {a.batch} images/step/GPU, one B=1 result "
-                                   f"per image (BASELINE.json configs[1])", "images_per_step": a.batch,
+                                   f"per image (BASELINE.json configs[1])" +
+                                   (f"; fixed set of {a.dataset} images round-robin over {world} GPU(s) "
+                                    f"(BASELINE.json configs[3])" if a.dataset > 0 else ""),
+                       "images_per_step": a.batch, "images_total": n_images,
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
-                       "accumulate": "fp32", "eig_dtype": "f32", "parallelism": f"dp{world} round-robin, 1 gather",
+                       "vit_operands": "f16" if dtype == torch.float16 else "bf16", "accumulate": "fp32",
+                       "affinity": os.environ.get("DSS_AFFINITY", "split") + ("-f16 (hi+lo f16 terms, fp32 accumulate)"
+                                                                              if os.environ.get("DSS_AFFINITY", "split") == "split" else ""),
+                       "w_dtype": "u16-fixed (round(65535 w))" if a.w_dtype == "u16" else "f32",
+                       "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
+                       "h2d_in_timed_region": not a.resident,
+                       "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
                        "stage_overlap": a.overlap, "gelu": a.gelu},
+            "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
-            "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
         }
+    if world == 1 and a.companion_steps > 0 and a.dataset == 0:
+        other = "f32" if a.w_dtype == "u16" else "u16"
+        for i in range(2):   # warm the other storage's kernels / allocations
+            feeder.prefetch(i)
+            step(model, feeder.get(i), a.K, a.vit_batch, a.overlap, a.vit_streams, other)
+            feeder.release(i)
+        torch.cuda.synchronize()
+        e2, _, _, _ = run_steps(model, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, other)
+        out[f"value_w_{other}"] = round(a.companion_steps * a.batch / e2, 2)
+    if rank == 0:
         if world == 1 and a.cpu_images > 0:
-            first = step(model, pool[: a.cpu_images + 1], a.K, a.vit_batch, a.overlap, a.vit_streams)
+            first = step(model, host[: a.cpu_images + 1].to(dev), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a.model, sd, a.size, a.K, a.cpu_images, first[1], first[0],
                                                               lam_tol=1e-3 if dtype == torch.float16 else 1e-2)
         print(json.dumps(out))

@@ -4,18 +4,19 @@
 // extract/extract.py:94):   attn = softmax((q @ k^T) * scale) ; x = (attn @ v).transpose(1,2).reshape(B,T,C)
 // The [h, T, T] score matrix is never materialised (flash-style online softmax).
 //
-// Two kernels:
-//  1. attn_pack: qkv [B,T,3,h,64] -> Q [B,h,Tp,64], K [B,h,Tp,64], V^T [B,h,64,Tp]  (Tp = T rounded up to
-//     64, zero padded).  V is transposed through LDS because the P.V contraction runs over keys, and an
-//     MFMA operand wants its contraction index contiguous per lane.  Inside every 16-key group V^T's
-//     keys are stored in the order the softmax registers hold them (see KEY ORDER) so one 16-byte load
-//     is one MFMA operand.
-//  2. attn_fwd: one wave = 32 query rows; per 32-key block
-//        S^T[key][q]  = mfma_32x32x16( K-fragment , Q-fragment )      (4 MFMAs, contraction over dh=64)
+// Kernels (both read the qkv tensor in place - interleaved [B,T,3,h,64] or DSS_PLANAR64 - and stage K/V tiles of 64
+// keys through registers into double-buffered LDS):
+//  * attn_fwd2: 4 waves x 64 queries per workgroup, one barrier per key tile; every wave runs
+//        S^T[key][q]  = mfma_32x32x16( K-fragment , Q-fragment )      (contraction over dh = 64)
 //        online softmax down each lane's own query column (16 registers + one lane^32 exchange)
-//        O^T[dh][q]  += mfma_32x32x16( V^T-fragment , P^T-fragment )  (4 MFMAs, contraction over 32 keys)
-//     Computing the TRANSPOSED score tile makes the softmax reduction lane-local and lets the fp32
-//     probabilities be packed straight into the B operand of the second MFMA - no LDS round trip.
+//        O^T[dh][q]  += mfma_32x32x16( V^T-fragment , P^T-fragment )  (contraction over 32 keys)
+//    back to back.  Computing the TRANSPOSED score tile makes the softmax reduction lane-local and lets the fp32
+//    probabilities be packed straight into the B operand of the second MFMA - no LDS round trip.
+//  * attn_fwd3 (default): the same arithmetic, 8 waves x 64 queries per workgroup in two groups that PING-PONG on
+//    every SIMD: while one group is in its matrix phase (P.V of the previous 32 keys + Q.K^T of the next 32: 16 MFMAs,
+//    nothing else but LDS fragment reads) the other runs its softmax phase (~140 VALU instructions, no MFMA), then they
+//    swap - see the kernel.  At head dim 64 the VALU work of the softmax is as long as the MFMA work; kept in one
+//    instruction stream the two serialise, split over the two waves of a SIMD they overlap by construction.
 //
 // MFMA layouts used (v_mfma_f32_32x32x16_{f16,bf16}; cdna_hip_programming.md §3):
 //   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + e], e = 0..7   (8 halves = 16 B)
@@ -26,175 +27,13 @@
 //
 // KEY ORDER.  After the first MFMA lane l (half hh = l>>5) holds, for its query, keys
 //   key(r) = (r&3) + 8*(r>>2) + 4*hh,  r = 0..15  of the 32-key block.  Registers 8t..8t+7 (t = 0,1) form
-// the B operand of P.V MFMA number t, i.e. operand slot (hh, e) carries key 16t + 8*(e>>2) + 4*hh + (e&3).
-// V^T therefore stores, at position 16t + 8*hh + e of each 32-key block, exactly that key.
-#include <stdlib.h>
-
+// the B operand of P.V MFMA number t, i.e. operand slot (hh, e) carries key 16t + 8*(e>>2) + 4*hh + (e&3); the
+// transposed LDS read of V (ds_read_b64_tr_b16) delivers V^T fragments in exactly that key order.
 #include "common.h"
 
 namespace dss {
 
 static constexpr int DH = 64;  // head dim of every DINO ViT
-
-__host__ __device__ inline int attn_tp(int T) { return (T + 63) / 64 * 64; }
-
-// position p (0..15) inside a 16-key group -> key offset inside the group
-__device__ __forceinline__ int vt_key_of_pos(int p) {
-  const int hh = p >> 3, e = p & 7;
-  return 8 * (e >> 2) + 4 * hh + (e & 3);
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void attn_pack_kernel(const T* __restrict__ qkv, T* __restrict__ Qp,
-                                                        T* __restrict__ Kp, T* __restrict__ Vt, int Tn,
-                                                        int Tp, int heads) {
-  typedef typename vec8<T>::type V8;
-  __shared__ __attribute__((aligned(16))) T vtile[64][DH + 8];  // +8 halves: 16-B row skew
-  const int tid = threadIdx.x;
-  const int t0 = blockIdx.x * 64;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int row = tid >> 2;       // token inside the tile
-  const int ch = (tid & 3) * 16;  // 16 halves per thread
-  const int tok = t0 + row;
-  const long src_row = ((long)b * Tn + tok) * 3 * heads * DH + (long)head * DH + ch;
-  const long dst_row = (((long)b * heads + head) * Tp + tok) * DH + ch;
-  V8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (T)0.f;
-  V8 q0 = z, q1 = z, k0 = z, k1 = z, v0 = z, v1 = z;
-  if (tok < Tn) {
-    const T* s = qkv + src_row;
-    q0 = *reinterpret_cast<const V8*>(s);
-    q1 = *reinterpret_cast<const V8*>(s + 8);
-    k0 = *reinterpret_cast<const V8*>(s + (long)heads * DH);
-    k1 = *reinterpret_cast<const V8*>(s + (long)heads * DH + 8);
-    v0 = *reinterpret_cast<const V8*>(s + 2L * heads * DH);
-    v1 = *reinterpret_cast<const V8*>(s + 2L * heads * DH + 8);
-  }
-  *reinterpret_cast<V8*>(Qp + dst_row) = q0;
-  *reinterpret_cast<V8*>(Qp + dst_row + 8) = q1;
-  *reinterpret_cast<V8*>(Kp + dst_row) = k0;
-  *reinterpret_cast<V8*>(Kp + dst_row + 8) = k1;
-  *reinterpret_cast<V8*>(&vtile[row][ch]) = v0;
-  *reinterpret_cast<V8*>(&vtile[row][ch + 8]) = v1;
-  __syncthreads();
-  // transposed write: thread -> (dh = tid>>2, 16 consecutive POSITIONS of the 64-key tile)
-  const int dh = tid >> 2;
-  const int p0 = (tid & 3) * 16;
-  V8 o0, o1;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    o0[i] = vtile[p0 + vt_key_of_pos(i)][dh];
-    o1[i] = vtile[p0 + vt_key_of_pos(8 + i)][dh];
-  }
-  T* d = Vt + (((long)b * heads + head) * DH + dh) * Tp + t0 + p0;
-  *reinterpret_cast<V8*>(d) = o0;
-  *reinterpret_cast<V8*>(d + 8) = o1;
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Qp, const T* __restrict__ Kp,
-                                                       const T* __restrict__ Vt, T* __restrict__ out, int Tn,
-                                                       int Tp, int heads, float scale_log2) {
-  typedef typename vec8<T>::type V8;
-  typedef typename vec4<T>::type V4;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int li = lane & 31;
-  const int hh = lane >> 5;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  if (q0 >= Tn) return;  // whole wave out of range (no block-level barrier in this kernel)
-  const long bh = (long)b * heads + head;
-  const T* Qb = Qp + bh * Tp * DH;
-  const T* Kb = Kp + bh * Tp * DH;
-  const T* Vb = Vt + bh * DH * Tp;
-
-  V8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-    qf[s] = *reinterpret_cast<const V8*>(Qb + (long)(q0 + li) * DH + 16 * s + 8 * hh);
-
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m = -1.0e30f, lsum = 0.f;
-
-  const int nkb = (Tn + 31) / 32;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int key0 = kb * 32;
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const V8 kf = *reinterpret_cast<const V8*>(Kb + (long)(key0 + li) * DH + 16 * sl + 8 * hh);
-      s = mfma32x32x16(kf, qf[sl], s);
-    }
-    const bool tail = key0 + 32 > Tn;
-    float mx = -1.0e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = s[r] * scale_log2;
-      if (tail) {
-        const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (key >= Tn) v = -INFINITY;
-      }
-      s[r] = v;
-      mx = fmaxf(mx, v);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-      rs += s[r];
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    lsum = lsum * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    V8 pb0, pb1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pb0[e] = from_f32<T>(s[e]);
-      pb1[e] = from_f32<T>(s[8 + e]);
-    }
-    const T* vrow0 = Vb + (long)li * Tp + key0 + 8 * hh;
-    const T* vrow1 = Vb + (long)(32 + li) * Tp + key0 + 8 * hh;
-    const V8 v00 = *reinterpret_cast<const V8*>(vrow0);
-    const V8 v01 = *reinterpret_cast<const V8*>(vrow0 + 16);
-    const V8 v10 = *reinterpret_cast<const V8*>(vrow1);
-    const V8 v11 = *reinterpret_cast<const V8*>(vrow1 + 16);
-    o0 = mfma32x32x16(v00, pb0, o0);
-    o0 = mfma32x32x16(v01, pb1, o0);
-    o1 = mfma32x32x16(v10, pb0, o1);
-    o1 = mfma32x32x16(v11, pb1, o1);
-  }
-
-  const int q = q0 + li;
-  if (q < Tn) {
-    const float inv = 1.0f / lsum;
-    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      V4 a, c;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = from_f32<T>(o0[4 * g + i] * inv);
-        c[i] = from_f32<T>(o1[4 * g + i] * inv);
-      }
-      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
-      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = c;
-    }
-  }
-}
-
 
 // ================================================================================================
 // v2: LDS-staged, 64 queries per wave, no pack pass.
@@ -252,7 +91,7 @@ template <class T>
 __device__ __forceinline__ void softmax_block(f32x16& s, float& m, float& mc, float& l, f32x16& o0, f32x16& o1,
                                               typename vec8<T>::type& pb0, typename vec8<T>::type& pb1, float c,
                                               bool tail, int key0, int hh, int Tn) {
-  if (tail) {
+  if (tail) {   // (attn_fwd3 passes tail = false: it masks through the MFMA accumulator's initial value instead)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -441,58 +280,289 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
   store_q(q0 + 32 + li, ob0, ob1, half_pair_sum(lb));
 }
 
+// ================================================================================================
+// v3: 8 waves in two ping-pong groups (X = waves 0-3, Y = waves 4-7; a workgroup's waves w and w + 4 share a SIMD).
+// Time is cut into PHASES separated by raw s_barriers.  In an M phase a wave issues nothing but MFMAs and the LDS
+// fragment reads that feed them: P.V of the previous 32-key half (8 MFMAs) and Q.K^T of the next half (8 MFMAs).  In a
+// V phase it runs the online softmax of the scores it just produced (~140 VALU instructions, no MFMA).  Group Y runs one
+// phase behind group X, so on every SIMD one wave is in M while its partner is in V:
+//
+//   phase      4t            4t+1            4t+2                 4t+3       (tile t = keys 64t..64t+63, halves 2t / 2t+1)
+//   X      M: PV(2t-1)     V: soft(2t)     M: PV(2t), QK(2t+1)  V: soft(2t+1)
+//             QK(2t)          frags(2t+1)     + restage            frags(2t+2)
+//   Y      V: soft(2t-1)   M: PV(2t-1)     V: soft(2t)          M: PV(2t), QK(2t+1)
+//             frags(2t)       QK(2t)          frags(2t+1) + restage
+//   frags(h) = the LDS fragment reads of the M phase of half h, issued at the end of the V phase before it;
+//   restage  = all waves write tile t+1 (global loads issued a tile earlier) into the other LDS buffer - it held tile
+//              t-1, whose last fragment reads (Y's frags(2t)) were issued before the barrier ending phase 4t; tile t+1
+//              is first read by X's frags(2t+2) in phase 4t+3 - and issue the global loads of tile t+2.
+// After the last tile X finishes with PV of the last half and Y with its softmax + PV.  Every wave passes the same
+// number of barriers whatever its queries (inactive waves still stage).
 template <class T>
-static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, void* ws,
-                             hipStream_t s, int impl, int planar) {
-  if (impl != 1) {  // v2 (default): LDS-staged, no pack pass, workspace unused
-    const int nqb = ceil_div(Tn, 256);
-    hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(256), 0, s, (const T*)qkv,
-                       (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
-    return;
+__global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+                                                           int heads, int nb, int nqb, float scale_log2,
+                                                           int planar) {
+  typedef typename vec8<T>::type V8;
+  typedef typename vec4<T>::type V4;
+  __shared__ __attribute__((aligned(16))) T Ks[2][64 * KLD];
+  __shared__ __attribute__((aligned(16))) T Vs[2][64 * VLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const bool group_x = wave < 4;
+  int qblk, group;
+  {  // XCD-aware block order: the query blocks of one (image, head) get ids congruent mod 8 (see attn_fwd2)
+    const int id = blockIdx.x, groups = heads * nb, g8 = groups & ~7;
+    if (id < nqb * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      group = (slot / nqb) * 8 + xcd;
+      qblk = slot % nqb;
+    } else {
+      const int r = id - nqb * g8;
+      group = g8 + r / nqb;
+      qblk = r % nqb;
+    }
   }
-  const int Tp = attn_tp(Tn);
-  const size_t panel = (size_t)B * heads * Tp * DH;
-  T* Qp = (T*)ws;
-  T* Kp = Qp + panel;
-  T* Vt = Kp + panel;
-  hipLaunchKernelGGL((attn_pack_kernel<T>), dim3(Tp / 64, heads, B), dim3(256), 0, s, (const T*)qkv, Qp, Kp,
-                     Vt, Tn, Tp, heads);
-  const float scale_log2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(ceil_div(Tn, 128), heads, B), dim3(256), 0, s, Qp, Kp, Vt,
-                     (T*)out, Tn, Tp, heads, scale_log2);
+  const int head = group % heads, b = group / heads;
+  const long plane = (long)nb * Tn * DH;
+  const long rs = planar ? DH : 3L * heads * DH;                    // row stride (halves)
+  const long koff = planar ? heads * plane : (long)heads * DH;      // q -> k ; q -> v is twice that
+  const T* base = planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
+  const int q0 = qblk * 512 + wave * 64;
+  // wave-uniform, and provably so for the compiler (scalar branches, no exec masking around the MFMAs).  A wave whose
+  // second 32-query block lies past the sequence computes it anyway on clamped rows (at most one wave per image and
+  // head; its partner on the SIMD is a full wave) and simply does not store it.
+  const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
+
+  // ---- Q fragments (registers, once) ---------------------------------------------------------------------
+  V8 qf0[4], qf1[4];
+  {
+    int qa = q0 + li, qb = q0 + 32 + li;
+    qa = qa < Tn ? qa : Tn - 1;
+    qb = qb < Tn ? qb : Tn - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf0[s] = *reinterpret_cast<const V8*>(base + (long)qa * rs + 16 * s + 8 * hh);
+      qf1[s] = *reinterpret_cast<const V8*>(base + (long)qb * rs + 16 * s + 8 * hh);
+    }
+  }
+  // ---- staging map: 512 threads x one 16-byte piece of K and of V per tile: row tid>>3, 8 halves at 8*(tid&7) ----
+  const int srow = tid >> 3, scol = (tid & 7) * 8;
+  V8 kreg, vreg;
+  auto stage_load = [&](int kt) {
+    const int key = kt * 64 + srow;
+    if (key < Tn) {
+      const T* p = base + (long)key * rs + scol;
+      kreg = *reinterpret_cast<const V8*>(p + koff);
+      vreg = *reinterpret_cast<const V8*>(p + 2 * koff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { kreg[i] = (T)0.f; vreg[i] = (T)0.f; }
+    }
+  };
+  auto stage_write = [&](int buf) {
+    *reinterpret_cast<V8*>(&Ks[buf][srow * KLD + scol]) = kreg;
+    *reinterpret_cast<V8*>(&Vs[buf][srow * VLD + scol]) = vreg;
+  };
+  // phase barrier: raw s_barrier (no release fence: the compiler would drain vmcnt - the prefetch of the next tile -
+  // in front of every barrier); LDS writes are awaited explicitly where a phase made any (after stage_write).
+  auto phase_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+  f32x16 oa0, oa1, ob0, ob1;   // O^T accumulators: query block a/b x dh block 0/1
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
+  float ma = -1.0e30f, mca = -1.0e30f * scale_log2, la = 0.f, mb = -1.0e30f, mcb = -1.0e30f * scale_log2, lb = 0.f;
+  f32x16 sa, sb;               // raw scores of the half in flight
+  V8 pa0, pa1, pb0, pb1;       // its probabilities, packed as P.V operands
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { pa0[e] = (T)0.f; pa1[e] = (T)0.f; pb0[e] = (T)0.f; pb1[e] = (T)0.f; }
+
+  const int nkt = (Tn + 63) / 64;
+  const int nh = (Tn + 31) / 32;          // halves holding at least one real key
+  const int tr_row = 4 * hh + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  // ---- LDS fragments of the M phase of half h (V^T of half h - 1, K of half h): 12 reads, 32 VGPRs.  Issued at the END
+  //      of the preceding V phase, in front of the barrier, so the MFMAs of the M phase start on operands that are
+  //      already in registers (an s_barrier does not wait for LDS reads in flight).
+  V8 vf[4], kf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { vf[i][e] = (T)0.f; kf[i][e] = (T)0.f; }
+  auto frag_load = [&](int h) {
+    if (!active) return;
+    if (h >= 1 && h - 1 < nh) {
+      const int g = h - 1;
+      const T* vbase = &Vs[(g >> 1) & 1][((g & 1) * 32 + tr_row) * VLD + tr_col];
+      vf[0] = lds_read_tr_pair<T>(vbase, vbase + 8 * VLD);                       // keys 0..15, dh 0..31
+      vf[1] = lds_read_tr_pair<T>(vbase + 32, vbase + 8 * VLD + 32);             // keys 0..15, dh 32..63
+      vf[2] = lds_read_tr_pair<T>(vbase + 16 * VLD, vbase + 24 * VLD);           // keys 16..31
+      vf[3] = lds_read_tr_pair<T>(vbase + 16 * VLD + 32, vbase + 24 * VLD + 32);
+    }
+    if (h < nh) {
+      const T* krow = &Ks[(h >> 1) & 1][((h & 1) * 32 + li) * KLD + 8 * hh];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) kf[sl] = *reinterpret_cast<const V8*>(krow + 16 * sl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- M phase of half h: O += V^T . P^T for half h - 1, then S = K . Q^T for half h: 16 MFMAs back to back.
+  //      Keys past the end of the sequence (last half only) are masked through the accumulator's INITIAL value (-inf in
+  //      their rows, 0 elsewhere: the MFMA adds it for free); full halves start from the inline constant 0.
+  auto m_phase = [&](int h) {
+    if (!active) return;
+    __builtin_amdgcn_s_setprio(1);
+    if (h >= 1 && h - 1 < nh) {
+      oa0 = mfma32x32x16(vf[0], pa0, oa0);
+      ob0 = mfma32x32x16(vf[0], pb0, ob0);
+      oa1 = mfma32x32x16(vf[1], pa0, oa1);
+      ob1 = mfma32x32x16(vf[1], pb0, ob1);
+      oa0 = mfma32x32x16(vf[2], pa1, oa0);
+      ob0 = mfma32x32x16(vf[2], pb1, ob0);
+      oa1 = mfma32x32x16(vf[3], pa1, oa1);
+      ob1 = mfma32x32x16(vf[3], pb1, ob1);
+    }
+    if (h < nh) {
+      if (h * 32 + 32 > Tn) {
+        f32x16 init;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) init[r] = (h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? 0.f : -INFINITY;
+        sa = init;
+        sb = init;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          sa = mfma32x32x16(kf[sl], qf0[sl], sa);
+          sb = mfma32x32x16(kf[sl], qf1[sl], sb);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          sa = mfma32x32x16(kf[sl], qf0[sl], sa);
+          sb = mfma32x32x16(kf[sl], qf1[sl], sb);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto v_phase = [&](int h) {            // softmax(h): scores -> packed probabilities, running max / sum
+    if (!active || h < 0 || h >= nh) return;
+    softmax_block<T>(sa, ma, mca, la, oa0, oa1, pa0, pa1, scale_log2, false, 0, hh, Tn);
+    softmax_block<T>(sb, mb, mcb, lb, ob0, ob1, pb0, pb1, scale_log2, false, 0, hh, Tn);
+  };
+  // tile t + 1 goes into the other LDS buffer in phase 4t + 2 (that buffer held tile t - 1, whose last fragment reads
+  // were issued before the barrier that ended phase 4t), and its global loads were issued a whole tile earlier
+  auto restage = [&](int t) {
+    if (t + 1 < nkt) { stage_write((t + 1) & 1); lds_done(); }
+    if (t + 2 < nkt) stage_load(t + 2);
+  };
+
+  stage_load(0);
+  stage_write(0);
+  if (nkt > 1) stage_load(1);
+  lds_done();
+  __syncthreads();
+  if (group_x) {
+    frag_load(0);
+    for (int t = 0; t < nkt; ++t) {
+      m_phase(2 * t);                                      // phase 4t
+      phase_barrier();
+      v_phase(2 * t);                                      // phase 4t + 1
+      frag_load(2 * t + 1);
+      phase_barrier();
+      restage(t);                                          // phase 4t + 2
+      m_phase(2 * t + 1);
+      phase_barrier();
+      v_phase(2 * t + 1);                                  // phase 4t + 3
+      frag_load(2 * t + 2);
+      phase_barrier();
+    }
+    m_phase(2 * nkt);                                      // P.V of the last half
+    phase_barrier();
+    phase_barrier();
+  } else {
+    for (int t = 0; t < nkt; ++t) {
+      v_phase(2 * t - 1);                                  // phase 4t
+      frag_load(2 * t);
+      phase_barrier();
+      m_phase(2 * t);                                      // phase 4t + 1
+      phase_barrier();
+      restage(t);                                          // phase 4t + 2
+      v_phase(2 * t);
+      frag_load(2 * t + 1);
+      phase_barrier();
+      m_phase(2 * t + 1);                                  // phase 4t + 3
+      phase_barrier();
+    }
+    v_phase(2 * nkt - 1);
+    frag_load(2 * nkt);
+    phase_barrier();
+    m_phase(2 * nkt);
+    phase_barrier();
+  }
+
+  if (!active) return;
+  auto store_q = [&](int q, const f32x16& x0, const f32x16& x1, float l) {
+    if (q >= Tn) return;
+    const float inv = 1.0f / l;
+    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      V4 a, c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = from_f32<T>(x0[4 * g + i] * inv);
+        c[i] = from_f32<T>(x1[4 * g + i] * inv);
+      }
+      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
+      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = c;
+    }
+  };
+  store_q(q0 + li, oa0, oa1, half_pair_sum(la));       // the two half-waves hold disjoint keys of each query
+  store_q(q0 + 32 + li, ob0, ob1, half_pair_sum(lb));
 }
 
-// DSS_ATTENTION_IMPL=1 selects the v1 kernel pair (pack + register-direct); anything else the LDS-staged v2.
-static int attention_impl() {
-  const char* env = getenv("DSS_ATTENTION_IMPL");
-  return env ? atoi(env) : 2;
+template <class T>
+static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
+                             int variant, int planar) {
+  const float scale_log2 = scale * 1.4426950408889634f;
+  if (variant == DSS_ATTENTION_4WAVE) {
+    const int nqb = ceil_div(Tn, 256);
+    hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(256), 0, s, (const T*)qkv,
+                       (T*)out, Tn, heads, B, nqb, scale_log2, planar);
+  } else {
+    const int nqb = ceil_div(Tn, 512);
+    hipLaunchKernelGGL((attn_fwd3_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(512), 0, s, (const T*)qkv,
+                       (T*)out, Tn, heads, B, nqb, scale_log2, planar);
+  }
 }
 
 }  // namespace dss
 
-extern "C" size_t dss_attention_workspace_bytes(int B, int T, int heads) {
-  if (B <= 0 || T <= 0 || heads <= 0) return 0;
-  if (dss::attention_impl() != 1) return 0;  // the default LDS-staged kernel reads qkv in place
-  return (size_t)3 * B * heads * dss::attn_tp(T) * dss::DH * 2;
-}
-
 extern "C" int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, int heads, float scale,
-                                 int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int dtype, int variant, void* stream) {
   DSS_REQUIRE(qkv && out, "dss_attention_fwd: null pointer");
   DSS_REQUIRE(qkv_layout == DSS_ROW_MAJOR || qkv_layout == DSS_PLANAR64,
               "dss_attention_fwd: qkv_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", qkv_layout);
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
-  DSS_REQUIRE(B <= 65535 && heads <= 65535, "dss_attention_fwd: B and heads must be <= 65535");
-  const size_t need = dss_attention_workspace_bytes(B, T, heads);
-  if (need && (!workspace || workspace_bytes < need))
-    return dss::fail(DSS_ERR_WORKSPACE, "dss_attention_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+  DSS_REQUIRE((long)B * heads * dss::ceil_div(T, 256) < 2147483647L, "dss_attention_fwd: too many workgroups");
+  DSS_REQUIRE(variant == DSS_ATTENTION_DEFAULT || variant == DSS_ATTENTION_4WAVE || variant == DSS_ATTENTION_PINGPONG,
+              "dss_attention_fwd: unknown variant %d", variant);
+  if (variant == DSS_ATTENTION_DEFAULT) variant = DSS_ATTENTION_PINGPONG;
   hipStream_t s = (hipStream_t)stream;
-  const int impl = dss::attention_impl();
   const int planar = qkv_layout == DSS_PLANAR64;
-  DSS_REQUIRE(!(planar && impl == 1), "dss_attention_fwd: DSS_ATTENTION_IMPL=1 reads interleaved qkv only");
   switch (dtype) {
-    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, workspace, s, impl, planar); break;
-    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, workspace, s, impl, planar); break;
+    case DSS_F16: dss::launch_attention<dss::f16>(qkv, out, B, T, heads, scale, s, variant, planar); break;
+    case DSS_BF16: dss::launch_attention<dss::bf16>(qkv, out, B, T, heads, scale, s, variant, planar); break;
     default: return dss::fail(DSS_ERR_BAD_ARG, "dss_attention_fwd: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
   }
   DSS_CHECK_LAUNCH("attention");

@@ -1,7 +1,5 @@
 // eigs.hip - kernel wrappers + C ABI for the Laplacian eigen stage (algorithm: eigs_core.h) and the
 // stand-alone sign rule.
-#include <stdlib.h>
-
 #include "common.h"
 #include "eigs_core.h"
 
@@ -82,11 +80,9 @@ static int symmetric_eigs(const WE* W, int B, int N, int K, int mode, float* eig
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
   if (e != hipSuccess)
     return fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
-  // 512-thread workgroups (default) let two images share a CU: the serial Rayleigh-Ritz / restart phases of one
-  // overlap the W streaming of the other.  DSS_EIGS_THREADS=1024 selects one 16-wave workgroup per CU.
-  const char* env = getenv("DSS_EIGS_THREADS");
-  int threads = env ? atoi(env) : 512;
-  if (threads != 256 && threads != 512 && threads != 1024) threads = 512;
+  // 512-thread workgroups let two images share a CU: the serial Rayleigh-Ritz / restart phases of one overlap the W
+  // streaming of the other (measured against one 16-wave workgroup per CU in round 1).
+  const int threads = 512;
   hipLaunchKernelGGL(laplacian_eigs_kernel<WE>, dim3(B), dim3(threads), L.total, (hipStream_t)stream, W, P,
                      (float*)workspace, per_img, eigenvalues, eigenvectors, info);
   DSS_CHECK_LAUNCH("laplacian_eigs");

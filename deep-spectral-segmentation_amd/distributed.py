@@ -7,10 +7,12 @@ shards embarrassingly:
   * rank ``r`` owns items ``i % world == r`` of the SORTED, de-duplicated work list - the order
     extract_utils.py:23 / extract.py:279 define;
   * there is no collective on the data path;
-  * results are collected on rank 0 with one gather (RCCL over xGMI when the backend is ``nccl``): each
-    rank contributes one packed f32 buffer ``[n_r, K*N + K + 1]`` (eigenvectors, eigenvalues, item id).
-    xGMI is point-to-point, so a gather-to-root is 7 concurrent receives, one per link; with <= 180 MB
-    for 10k images it is bounded by per-link bandwidth (~153 GB/s), not by a ring.
+  * results are collected on rank 0 once, at the end (RCCL over xGMI when the backend is ``nccl``): sizes first
+    (an int64 ``[n_r, 3]`` table of item id, N, K per result), then ONE flat f32 payload per rank (eigenvectors then
+    eigenvalues of every result, back to back) received point to point - xGMI is point-to-point, so the gather is 7
+    concurrent receives, one per link, of exactly the bytes each rank produced; with <= 180 MB for 10k images (C4) or
+    <= 5 GB (C5, mixed N) it is bounded by per-link bandwidth (~153 GB/s), not by a ring.  Item ids travel as
+    int64, never through a float.
 """
 from __future__ import annotations
 
@@ -91,3 +93,71 @@ def gather_to_root(packed: torch.Tensor, n_total: int):
     allrows = torch.cat(out)
     allrows = allrows[allrows[:, -1] >= 0]
     return allrows[torch.argsort(allrows[:, -1])]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Variable-size records (BASELINE config 5: mixed image sizes -> a different N per result): sizes first, then one
+# flat payload per rank.
+def pack_records(ids, eigenvalues, eigenvectors) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One or several same-shape groups of results -> ``(meta int64 [n, 3] = (id, N, K), payload f32 flat)``.
+    ``ids [n]``, ``eigenvalues [n, K]``, ``eigenvectors [n, K, N]``; pass lists of such tensors for several groups
+    (each with its own N / K).  Per result the payload holds the ``K*N`` eigenvector values, then the ``K`` eigenvalues."""
+    if torch.is_tensor(ids):
+        ids, eigenvalues, eigenvectors = [ids], [eigenvalues], [eigenvectors]
+    metas, flats = [], []
+    for i, ev, vec in zip(ids, eigenvalues, eigenvectors):
+        n, k, nn = vec.shape
+        dev = vec.device
+        metas.append(torch.stack((i.to(dev, torch.int64), torch.full((n,), nn, dtype=torch.int64, device=dev),
+                                  torch.full((n,), k, dtype=torch.int64, device=dev)), dim=1))
+        flats.append(torch.cat((vec.reshape(n, -1).float(), ev.float()), dim=1).reshape(-1))
+    return torch.cat(metas), torch.cat(flats)
+
+
+def unpack_records(meta: torch.Tensor, payload: torch.Tensor):
+    """Inverse of ``pack_records``: list of ``(id, eigenvalues [K], eigenvectors [K, N])`` in ``meta`` order."""
+    out, off = [], 0
+    for item, n, k in meta.tolist():
+        vec = payload[off:off + k * n].reshape(k, n)
+        val = payload[off + k * n:off + k * n + k]
+        out.append((item, val, vec))
+        off += k * n + k
+    assert off == payload.numel(), (off, payload.numel())
+    return out
+
+
+def gather_records_to_root(meta: torch.Tensor, payload: torch.Tensor):
+    """The run's single collection step: every rank's ``(meta, payload)`` -> rank 0, which returns them concatenated
+    and ordered by item id (``None`` on the other ranks).  Two rounds: the ``[world, 2]`` table of (records, floats)
+    per rank, then point-to-point receives of exactly those sizes (all posted at once: 7 concurrent xGMI links)."""
+    rank, world = rank_world()
+    if world > 1 and dist.is_initialized():
+        dev = payload.device if dist.get_backend() != "gloo" else torch.device("cpu")  # gloo moves host tensors
+        meta, payload = meta.to(dev).contiguous(), payload.to(dev).contiguous()
+        mine = torch.tensor([meta.shape[0], payload.numel()], dtype=torch.int64, device=dev)
+        sizes = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, sizes, dst=0)                                    # round 1: sizes
+        if rank != 0:
+            ops = [dist.P2POp(dist.isend, meta.reshape(-1), 0), dist.P2POp(dist.isend, payload, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return None
+        metas, flats, ops = [meta], [payload], []
+        for r in range(1, world):
+            n_r, f_r = (int(v) for v in sizes[r].tolist())
+            metas.append(torch.empty((n_r, 3), dtype=torch.int64, device=dev))
+            flats.append(torch.empty((f_r,), dtype=torch.float32, device=dev))
+            ops += [dist.P2POp(dist.irecv, metas[-1].view(-1), r), dist.P2POp(dist.irecv, flats[-1], r)]
+        if ops:                                                            # round 2: the flat payloads
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        meta, payload = torch.cat(metas), torch.cat(flats)
+    # order by item id: per-record offsets into the concatenated payload
+    lens = meta[:, 1] * meta[:, 2] + meta[:, 2]
+    offs = torch.cumsum(lens, 0) - lens
+    order = torch.argsort(meta[:, 0])
+    if bool((lens == lens[0]).all()):      # one N: a plain row permutation
+        payload = payload.reshape(meta.shape[0], -1)[order].reshape(-1)
+    else:
+        payload = torch.cat([payload[int(o):int(o) + int(l)] for o, l in zip(offs[order].tolist(), lens[order].tolist())])
+    return meta[order], payload

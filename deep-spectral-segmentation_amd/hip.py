@@ -28,9 +28,7 @@ SYMBOLS = {
     "dss_preprocess_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_float, c_void_p]),
-    "dss_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
-                                  c_void_p]),
+    "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_mlp_k384_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -184,30 +182,26 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
-def attention_workspace_bytes(b: int, t: int, heads: int) -> int:
-    return int(load_library().dss_attention_workspace_bytes(b, t, heads))
+ATTENTION_DEFAULT, ATTENTION_4WAVE, ATTENTION_PINGPONG = 0, 2, 3   # dss_attention_fwd `variant` (include/dss_hip.h)
 
 
-def attention(qkv: torch.Tensor, heads: int, scale: float, workspace: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None, planar_bt: Optional[tuple] = None) -> torch.Tensor:
+def attention(qkv: torch.Tensor, heads: int, scale: float, out: Optional[torch.Tensor] = None,
+              planar_bt: Optional[tuple] = None, variant: int = ATTENTION_DEFAULT) -> torch.Tensor:
     """``qkv`` ``[B, T, 3*heads*64]`` (fp16/bf16) -> ``[B, T, heads*64]``.  With ``planar_bt=(B, T)`` ``qkv`` is the
-    DSS_PLANAR64 form ``[3*heads, B*T, 64]`` written by ``linear_k384(..., planar=True)``."""
+    DSS_PLANAR64 form ``[3*heads, B*T, 64]`` written by ``linear_k384(..., planar=True)``.  ``variant`` selects the
+    kernel (default: the 8-wave ping-pong kernel; ``ATTENTION_4WAVE`` the 4-wave one - A/B runs and tests)."""
     if planar_bt is None:
         b, t, c3 = qkv.shape
         assert c3 == 3 * heads * 64, "head dim must be 64"
     else:
         b, t = planar_bt
         assert tuple(qkv.shape) == (3 * heads, b * t, 64), "planar qkv must be [3*heads, B*T, 64]"
-    need = attention_workspace_bytes(b, t, heads)
-    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
-        workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
-    wptr, wbytes = (0, 0) if not need else (_dev(workspace, "workspace"), workspace.numel() * workspace.element_size())
     if out is None:
         out = torch.empty((b, t, heads * 64), dtype=qkv.dtype, device=qkv.device)
     with _timed("attention", b=b, t=t, heads=heads):
         _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), ROW_MAJOR if planar_bt is None else PLANAR64,
                                                 _dev(out, "out"), b, t, heads, float(scale),
-                                                dtype_code(qkv.dtype), wptr, wbytes, _stream()),
+                                                dtype_code(qkv.dtype), int(variant), _stream()),
                "dss_attention_fwd")
     return out
 

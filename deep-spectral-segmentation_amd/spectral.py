@@ -94,7 +94,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
                                  max_restarts: int = 0, max_bytes: int = 24 << 30, strict: bool = True,
                                  affinity_mode: Optional[str] = None, retry: bool = True,
                                  problem: str = "laplacian",
-                                 upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None
+                                 upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None,
+                                 w_dtype: Optional[str] = None
                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
     ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
@@ -111,8 +112,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
       bilinearly (``align_corners=False``) from the patch grid to the low-resolution pixel grid before the affinity.
     * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
       (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.  With the default recipe (``problem="laplacian"``,
-      ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``$DSS_W_DTYPE=f32`` keeps
-      floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
+      ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``w_dtype="f32"`` /
+      ``$DSS_W_DTYPE=f32`` keeps floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
       Checking for them reads ``info`` back (one device->host sync per call): throughput loops that must keep
       the host running ahead pass ``retry=False, strict=False`` and inspect ``info`` once at the end.
@@ -156,8 +157,12 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     # W as 16-bit fixed point (half the bytes of the solver's only HBM stream) whenever the problem allows it: the
     # normalised Laplacian is invariant to the scale of W, and normalised + thresholded similarities lie in [0, 1]
     # (after an upsample the rows are interpolated, not re-normalised: |w| <= 1 still holds, but keep f32 there).
+    if w_dtype is None:
+        w_dtype = os.environ.get("DSS_W_DTYPE", "u16")
+    if w_dtype not in ("u16", "f32"):
+        raise ValueError(f"w_dtype must be 'u16' or 'f32' (got {w_dtype!r})")
     w_u16 = (problem == "laplacian" and normalize and threshold_at_zero and upsample is None and d % 32 == 0
-             and affinity_mode == "split" and os.environ.get("DSS_W_DTYPE", "u16") == "u16")
+             and affinity_mode == "split" and w_dtype == "u16")
     ld = hip.affinity_ld(n)
     per_image = hip.affinity_elems(n) * (2 if w_u16 else 4) + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
@@ -189,7 +194,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         ev2, vec2, info2 = laplacian_eigs_from_features(
             feats[bad], K, normalize=normalize, threshold_at_zero=threshold_at_zero, ncv=64,
             tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60), max_bytes=max_bytes,
-            strict=False, affinity_mode=affinity_mode, retry=False, problem="_raw_" + problem, upsample=None)
+            strict=False, affinity_mode=affinity_mode, retry=False, problem="_raw_" + problem, upsample=None,
+            w_dtype=w_dtype)
         ev[bad], vec[bad], info[bad] = ev2, vec2, info2
         still = (info <= 0).nonzero().flatten()
         if still.numel():   # last resort, like the reference's second eigsh call: it always produces an answer

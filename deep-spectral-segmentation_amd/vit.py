@@ -150,7 +150,6 @@ class DinoViT:
         self.scale = 64 ** -0.5
         assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
         self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._attn_ws: Optional[torch.Tensor] = None
         hip.load_library()  # fail now, not mid-run, if the kernels are missing
         setup_gemm_tuning()
 
@@ -163,14 +162,6 @@ class DinoViT:
             cls_row = (self.cls_token[0, 0] + pe[0, 0]).to(self.device)
             self._pos_cache[key] = (cls_row.contiguous(), pe[0, 1:].to(self.device).contiguous())
         return self._pos_cache[key]
-
-    def _attn_workspace(self, b: int, t: int) -> Optional[torch.Tensor]:
-        need = hip.attention_workspace_bytes(b, t, self.num_heads)
-        if need == 0:
-            return None
-        if self._attn_ws is None or self._attn_ws.numel() < need:
-            self._attn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._attn_ws
 
     @torch.no_grad()
     def extract_k(self, img_u8: torch.Tensor, which_block: int = -1) -> torch.Tensor:
@@ -193,7 +184,6 @@ class DinoViT:
         x = torch.empty((b, t, d), dtype=torch.float32, device=self.device)  # fp32 residual stream
         x[:, 0] = cls_row
         torch.add(tok, pos, out=x[:, 1:])
-        ws = self._attn_workspace(b, t)
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
         # K-resident Linear kernel: at D = 384 it beats the library GEMM on qkv, proj and fc1+GELU.  At D = 768 (one
@@ -208,13 +198,13 @@ class DinoViT:
             hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             if k384:
                 qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)       # [3h, B*T, 64]
-                o = hip.attention(qkv, heads, self.scale, workspace=ws, planar_bt=(b, t))
+                o = hip.attention(qkv, heads, self.scale, planar_bt=(b, t))
                 pending = hip.linear_kres(o, blk["proj_w"], blk["proj_b"], planar=True)    # [D/64, B*T, 64]
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
                                      residual_planar=True)
             else:
                 qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
-                o = hip.attention(qkv, heads, self.scale, workspace=ws)
+                o = hip.attention(qkv, heads, self.scale)
                 pending = F.linear(o, blk["proj_w"], blk["proj_b"])
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
             if self.mlp_fused and d == 384 and self.gelu == "erf":

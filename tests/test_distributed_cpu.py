@@ -1,4 +1,5 @@
-"""CPU, world_size 2 over gloo: the N>1 path (round-robin shard + single gather to rank 0)."""
+"""CPU, world_size 2 over gloo: the N>1 path - round-robin shards (uneven), the fixed-size gather and the
+sizes-first / flat-payload gather for results of DIFFERENT N (BASELINE config 5), item ids as int64."""
 import os
 import socket
 
@@ -9,12 +10,17 @@ import torch.multiprocessing as mp
 import dss_amd  # noqa: F401
 from dss_amd import distributed
 
-K, N, TOTAL = 3, 11, 9
+K, N, TOTAL = 3, 11, 9          # 9 items over 2 ranks: shards of 5 and 4
+BIG_ID = (1 << 40) + 7          # an id no float32 can carry
 
 
-def _fake_result(i):
+def _fake_result(i, n=N, k=K):
     g = torch.Generator().manual_seed(1000 + i)
-    return torch.randn(K, generator=g), torch.randn(K, N, generator=g)
+    return torch.randn(k, generator=g), torch.randn(k, n, generator=g)
+
+
+def _shape_of(i):               # mixed sizes: two different N (and K) interleaved over the items
+    return (N, K) if i % 3 else (N + 6, K + 1)
 
 
 def _worker(rank, world, port, q):
@@ -22,19 +28,42 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert distributed.rank_world() == (rank, world)
     mine = distributed.shard_indices(TOTAL, rank, world)
+    assert len(mine) == (5 if rank == 0 else 4)
+    # ---- fixed N: the packed-row gather ------------------------------------------------------------------
     vals = torch.stack([_fake_result(i)[0] for i in mine])
     vecs = torch.stack([_fake_result(i)[1] for i in mine])
-    packed = distributed.pack_results(torch.tensor(mine), vals, vecs)
-    out = distributed.gather_to_root(packed, TOTAL)
+    out = distributed.gather_to_root(distributed.pack_results(torch.tensor(mine), vals, vecs), TOTAL)
+    ok = True
     if rank == 0:
         ids, v, e = distributed.unpack_results(out, K, N)
         ok = ids.tolist() == list(range(TOTAL))
         for i in range(TOTAL):
             rv, re = _fake_result(i)
             ok = ok and torch.equal(v[i], rv) and torch.equal(e[i], re)
-        q.put(ok)
     else:
         assert out is None
+    # ---- mixed N: sizes first, then one flat payload per rank --------------------------------------------
+    groups = {}
+    for i in mine:
+        groups.setdefault(_shape_of(i), []).append(i)
+    ids, evs, vcs = [], [], []
+    for (n, k), items in groups.items():
+        ids.append(torch.tensor([BIG_ID + i for i in items], dtype=torch.int64))
+        evs.append(torch.stack([_fake_result(i, n, k)[0] for i in items]))
+        vcs.append(torch.stack([_fake_result(i, n, k)[1] for i in items]))
+    got = distributed.gather_records_to_root(*distributed.pack_records(ids, evs, vcs))
+    if rank == 0:
+        meta, payload = got
+        assert meta.dtype == torch.int64
+        recs = distributed.unpack_records(meta, payload)
+        ok = ok and [r[0] for r in recs] == [BIG_ID + i for i in range(TOTAL)]
+        for i, (item, val, vec) in enumerate(recs):
+            n, k = _shape_of(i)
+            rv, re = _fake_result(i, n, k)
+            ok = ok and tuple(vec.shape) == (k, n) and torch.equal(val, rv) and torch.equal(vec, re)
+        q.put(ok)
+    else:
+        assert got is None
     dist.barrier()
     dist.destroy_process_group()
 

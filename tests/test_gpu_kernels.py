@@ -190,14 +190,14 @@ def _attention_ref(qkv, heads, scale):
 
 
 @pytest.mark.parametrize("b,t,heads", [(2, 901, 6), (1, 197, 6), (1, 17, 2), (1, 64, 1), (1, 65, 1), (3, 130, 12),
-                                        (1, 1, 1), (1, 33, 3), (1, 3601, 2), (2, 257, 2), (1, 320, 1)])
+                                        (1, 1, 1), (1, 33, 3), (1, 3601, 2), (2, 257, 2), (1, 320, 1), (1, 513, 2),
+                                        (2, 545, 1), (1, 577, 3), (1, 96, 2), (1, 1025, 1)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("impl", ["2", "1"])  # 2 = LDS-staged kernel (default), 1 = pack + register-direct kernel
-def test_attention_matches_fp64_reference(b, t, heads, dtype, impl, monkeypatch):
-    monkeypatch.setenv("DSS_ATTENTION_IMPL", impl)
+@pytest.mark.parametrize("variant", [hip.ATTENTION_PINGPONG, hip.ATTENTION_4WAVE], ids=["pingpong8", "4wave"])
+def test_attention_matches_fp64_reference(b, t, heads, dtype, variant):
     g = torch.Generator().manual_seed(b * 100 + t + heads)
     qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 1.5).to(dtype)
-    out = hip.attention(qkv.to(DEV), heads, 0.125).cpu()
+    out = hip.attention(qkv.to(DEV), heads, 0.125, variant=variant).cpu()
     ref = _attention_ref(qkv, heads, 0.125)
     err = (out.double() - ref).abs().max().item()
     tol = 4e-3 if dtype == torch.float16 else 3e-2
@@ -215,19 +215,32 @@ def test_attention_planar_qkv_is_bit_identical_to_interleaved(b, t, heads):
     assert torch.equal(a, p)
 
 
-@pytest.mark.parametrize("impl", ["2", "1"])
-def test_attention_peaked_rows_force_online_rescale(impl, monkeypatch):
+@pytest.mark.parametrize("variant", [hip.ATTENTION_PINGPONG, hip.ATTENTION_4WAVE], ids=["pingpong8", "4wave"])
+def test_attention_peaked_rows_force_online_rescale(variant):
     """One key far above the rest late in the sequence: the running max jumps, exercising the rescale."""
-    monkeypatch.setenv("DSS_ATTENTION_IMPL", impl)
     b, t, heads = 1, 300, 2
     g = torch.Generator().manual_seed(3)
     qkv = torch.randn(b, t, 3, heads, 64, generator=g) * 0.3
     qkv[0, 250, 1] = qkv[0, 7, 0] * 40.0   # key 250 aligned with query 7 (both heads)
     qkv[0, 40, 1] = qkv[0, 9, 0] * 25.0
     qkv = qkv.reshape(b, t, -1).half()
-    out = hip.attention(qkv.to(DEV), heads, 0.125).cpu()
+    out = hip.attention(qkv.to(DEV), heads, 0.125, variant=variant).cpu()
     ref = _attention_ref(qkv, heads, 0.125)
     assert (out.double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_attention_variants_agree_on_a_full_batch():
+    """The two kernels on the bench shape (many workgroups, every XCD, ragged last query block): same values up to
+    fp32 summation order; and repeated launches of the ping-pong kernel are bit-identical (no race between its
+    phases and the LDS restaging)."""
+    b, t, heads = 24, 901, 6
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 1.2).half().to(DEV)
+    a = hip.attention(qkv, heads, 0.125, variant=hip.ATTENTION_PINGPONG)
+    c = hip.attention(qkv, heads, 0.125, variant=hip.ATTENTION_4WAVE)
+    assert (a.float() - c.float()).abs().max().item() <= 2e-3
+    for _ in range(5):
+        assert torch.equal(a, hip.attention(qkv, heads, 0.125, variant=hip.ATTENTION_PINGPONG))
 
 
 # ----------------------------------------------------------------------------- normalise + affinity
