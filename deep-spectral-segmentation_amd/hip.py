@@ -28,7 +28,7 @@ SYMBOLS = {
     "dss_preprocess_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_float, c_void_p]),
-    "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_mlp_k384_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -182,14 +182,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
-ATTENTION_DEFAULT, ATTENTION_4WAVE, ATTENTION_PINGPONG = 0, 2, 3   # dss_attention_fwd `variant` (include/dss_hip.h)
-
-
 def attention(qkv: torch.Tensor, heads: int, scale: float, out: Optional[torch.Tensor] = None,
-              planar_bt: Optional[tuple] = None, variant: int = ATTENTION_DEFAULT) -> torch.Tensor:
+              planar_bt: Optional[tuple] = None) -> torch.Tensor:
     """``qkv`` ``[B, T, 3*heads*64]`` (fp16/bf16) -> ``[B, T, heads*64]``.  With ``planar_bt=(B, T)`` ``qkv`` is the
-    DSS_PLANAR64 form ``[3*heads, B*T, 64]`` written by ``linear_k384(..., planar=True)``.  ``variant`` selects the
-    kernel (default: the 8-wave ping-pong kernel; ``ATTENTION_4WAVE`` the 4-wave one - A/B runs and tests)."""
+    DSS_PLANAR64 form ``[3*heads, B*T, 64]`` written by ``linear_k384(..., planar=True)``."""
     if planar_bt is None:
         b, t, c3 = qkv.shape
         assert c3 == 3 * heads * 64, "head dim must be 64"
@@ -201,7 +197,7 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, out: Optional[torch.T
     with _timed("attention", b=b, t=t, heads=heads):
         _check(load_library().dss_attention_fwd(_dev(qkv, "qkv"), ROW_MAJOR if planar_bt is None else PLANAR64,
                                                 _dev(out, "out"), b, t, heads, float(scale),
-                                                dtype_code(qkv.dtype), int(variant), _stream()),
+                                                dtype_code(qkv.dtype), _stream()),
                "dss_attention_fwd")
     return out
 

@@ -12,8 +12,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Every call
  *     only ENQUEUES work on that stream and returns; nothing synchronises, nothing allocates.
  *   - Return value: DSS_OK (0) or a negative DSS_ERR_* code; dss_last_error() gives the message
- *     (thread-local).  Functions are re-entrant; there is no global mutable state and no environment variable is
- *     read: every choice of kernel variant is an argument.
+ *     (thread-local).  Functions are re-entrant; there is no global mutable state and no environment variable is read.
  *   - Half-precision dtypes: DSS_F16 (IEEE binary16) / DSS_BF16; DSS_F32 where noted.
  */
 #ifndef DSS_HIP_H
@@ -78,14 +77,9 @@ int dss_layernorm_fwd(float* x, const void* residual, int res_dtype, int res_lay
  *      the same [B*T, 3*heads*64] matrix in DSS_PLANAR64 layout (plane index = which * heads + head);
  * out: [B, T, heads*64] in `dtype`  = softmax(q k^T * scale) v, heads re-interleaved as the
  * reference's `.transpose(1, 2).reshape(B, T, C)`.  fp32 accumulation and softmax statistics.
- * variant: which kernel runs (an explicit argument - the library reads no environment variables):
- *   DSS_ATTENTION_DEFAULT (0)  the library's choice (= DSS_ATTENTION_PINGPONG);
- *   DSS_ATTENTION_4WAVE   (2)  4 waves x 64 queries per workgroup, QK^T / softmax / PV back to back in every wave;
- *   DSS_ATTENTION_PINGPONG(3)  8 waves x 64 queries in two groups alternating matrix and softmax phases (attention.hip).
- * Both read qkv in place (no workspace) and produce the same values up to fp32 summation order. */
-enum { DSS_ATTENTION_DEFAULT = 0, DSS_ATTENTION_4WAVE = 2, DSS_ATTENTION_PINGPONG = 3 };
+ * qkv is read in place (no workspace); one kernel: 8 waves x 32 queries per workgroup, four waves per SIMD (attention.hip). */
 int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, int heads, float scale, int dtype,
-                      int variant, void* stream);
+                      void* stream);
 
 /* ---- a6: Linear layers whose reduction dimension is the embedding width (qkv / attn.proj / mlp.fc1 of DINO's Block)
  * C[M, N] = A[M, K] . W[N, K]^T + bias[N], optionally followed by the exact (erf) GELU of DINO's Mlp
