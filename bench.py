@@ -132,7 +132,8 @@ def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
         ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
     k = torch.cat(ks) if len(ks) > 1 else ks[0]
     # strict=False, retry=False: no device->host sync inside the step (convergence is checked once, after timing)
-    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype)
+    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype,
+                                                 affinity_mode=os.environ.get("DSS_AFFINITY", "fused"))
 
 
 class ImageFeeder:
@@ -206,7 +207,10 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s")
         elif name == "affinity":
             m = metas[0]
-            if os.environ.get("DSS_AFFINITY", "split") == "fp32":   # exact fp32 MFMA build: MFMA-bound
+            if m.get("fused"):   # one kernel, raw f32 features in, packed 16-bit W out: 4ND + N(N+1) algorithmic bytes
+                byts = (4.0 * m["n"] * m["d"] + 1.0 * m["n"] * (m["n"] + 1)) * m["b"]
+                entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            elif os.environ.get("DSS_AFFINITY", "fused") == "fp32":   # exact fp32 MFMA build: MFMA-bound
                 flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle: N(N+1)/2 dots of 2D flop
                 entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
@@ -433,8 +437,10 @@ def main():
                        "images_per_step": a.batch, "images_total": n_images,
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
                        "vit_operands": "f16" if dtype == torch.float16 else "bf16", "accumulate": "fp32",
-                       "affinity": os.environ.get("DSS_AFFINITY", "split") + ("-f16 (hi+lo f16 terms, fp32 accumulate)"
-                                                                              if os.environ.get("DSS_AFFINITY", "split") == "split" else ""),
+                       "affinity": {"fused": "fused normalise + f16-operand Gram (fp32 accumulate) -> u16 W, one kernel"
+                                             if a.w_dtype == "u16" else "split-f16 (hi+lo f16 terms, fp32 accumulate)",
+                                    "split": "split-f16 (hi+lo f16 terms, fp32 accumulate)",
+                                    "fp32": "exact fp32 MFMA"}[os.environ.get("DSS_AFFINITY", "fused")],
                        "w_dtype": "u16-fixed (round(65535 w))" if a.w_dtype == "u16" else "f32",
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
                        "h2d_in_timed_region": not a.resident,

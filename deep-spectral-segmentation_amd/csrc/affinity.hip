@@ -314,6 +314,165 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
   store_tile(acc11, 32, 32, act_r1 && act_c1);
 }
 
+
+// ================================================================================================
+// Fused affinity build of the DEFAULT recipe (normalize=True, threshold_at_zero=True, W as 16-bit fixed point):
+//   extract/extract.py:148      feats = F.normalize(feats, p=2, dim=-1)
+//   extract/extract.py:191-193  W = feats @ feats.T ; W = W * (W > 0)
+// in ONE kernel that reads the RAW fp32 features and writes the packed u16 tiles - HBM traffic == the algorithmic bytes
+// (4 N D in, N (N+1) out per image), where the split-f16 pair above moves 4 N D three times (normalise + split pass out
+// and back in).  Three things make that possible:
+//   * normalisation AFTER the product: W_ij = <x_i, x_j> / (|x_i| |x_j|), so a block streams raw panels and collects the
+//     squared norms of its own 128 + 128 rows on the way (v_dot2 on the values the MFMAs see, so W_ii = 1 exactly);
+//   * f16 operands, ONE v_mfma_f32_32x32x16_f16 per product (fp32 accumulate) instead of the three of the hi/lo split:
+//     BASELINE.json config 5 is "fp16 features + fp32 Laplacian eigensolve", the 16-bit W behind it is quantised to 7.6e-6
+//     anyway, and the rounding (2^-11 relative per feature: ~3e-5 absolute on w) moves the eigenvectors of the reference
+//     goldens by <= 3e-6 in cosine (tests/test_gpu_kernels.py) - the 1e-4 budget is untouched;
+//   * same tiling / packed symmetric output / XCD-aware block order as gram_split_kernel.
+// LDS: f16 panels [128][32 + 8] (80-byte rows: ds_read_b128 conflict-free) for A and B, + the 256 inverse norms.
+static constexpr int FK = 32;        // feature columns per stage
+static constexpr int FLD = FK + 8;   // halves per LDS row (80 B)
+
+__global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __restrict__ feats, uint16_t* __restrict__ W,
+                                                                int N, int D, int ldw, float eps, size_t w_stride,
+                                                                int nimg) {
+  __shared__ __attribute__((aligned(16))) f16 Ah[GB][FLD];
+  __shared__ __attribute__((aligned(16))) f16 Bh[GB][FLD];
+  __shared__ float rinv[2][GB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nt = ldw / 64, nbk = (nt + 1) / 2, nblk = nbk * (nbk + 1) / 2;
+  int img, rem;
+  {  // XCD-aware order: all blocks of one image share an XCD (see gram_relu_kernel): its panels are L2 hits after one read
+    const int id = blockIdx.x, g8 = nimg & ~7;
+    if (id < nblk * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      img = (slot / nblk) * 8 + xcd;
+      rem = slot % nblk;
+    } else {
+      const int r = id - nblk * g8;
+      img = g8 + r / nblk;
+      rem = r % nblk;
+    }
+  }
+  int bi = 0;
+  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
+  const int bj = bi + rem;
+  const int I0 = bi * GB, J0 = bj * GB;
+  const float* F = feats + (long)img * N * D;
+  uint16_t* Wb = W + img * w_stride;
+
+  const int ti = 2 * bi + wr, tj = 2 * bj + wc;
+  const bool quad = ti < nt && tj < nt && tj >= ti;
+  const int ri0 = I0 + wr * 64, cj0 = J0 + wc * 64;
+
+  // accXY: rows block X (0/1) x columns block Y (0/1) of the wave's 64 x 64 quadrant, computed TRANSPOSED: the MFMA's
+  // "A" operand carries the COLUMN panel and its "B" operand the ROW panel, so a lane owns one row of W and its registers
+  // run along the columns - 4 consecutive columns per register group = one 8-byte store of four u16 (the untransposed
+  // product leaves a lane with one column and 2-byte stores: 64 store instructions per lane instead of 16).
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  // staging map: 8 threads cover one 128-byte row segment (32 floats); 32 rows per pass, 4 passes per panel.
+  // A diagonal block (bi == bj) has ONE panel: its B loads, conversions and LDS image are skipped.
+  const bool diag = bi == bj;
+  const int srow = tid >> 3, scol = (tid & 7) * 4;
+  float ssa[4] = {0.f, 0.f, 0.f, 0.f}, ssb[4] = {0.f, 0.f, 0.f, 0.f};
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  f32x4 va[4], vb[4];
+  auto load_chunk = [&](int d0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      int ga = I0 + r; ga = ga < N ? ga : N - 1;  // clamp: rows past N are computed and discarded
+      va[p] = *reinterpret_cast<const f32x4*>(F + (long)ga * D + d0 + scol);
+      if (!diag) {
+        int gb = J0 + r; gb = gb < N ? gb : N - 1;
+        vb[p] = *reinterpret_cast<const f32x4*>(F + (long)gb * D + d0 + scol);
+      }
+    }
+  };
+  load_chunk(0);
+  const f16 (*Bp)[FLD] = diag ? Ah : Bh;
+  for (int d0 = 0; d0 < D; d0 += FK) {
+    // registers -> f16 -> LDS, squared norms of the ROUNDED values on the way
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      const h2 a0 = {(f16)va[p][0], (f16)va[p][1]}, a1 = {(f16)va[p][2], (f16)va[p][3]};
+      ssa[p] = __builtin_amdgcn_fdot2(a0, a0, ssa[p], false);
+      ssa[p] = __builtin_amdgcn_fdot2(a1, a1, ssa[p], false);
+      const f16x4 pa = {a0[0], a0[1], a1[0], a1[1]};
+      *reinterpret_cast<f16x4*>(&Ah[r][scol]) = pa;
+      if (!diag) {
+        const h2 b0 = {(f16)vb[p][0], (f16)vb[p][1]}, b1 = {(f16)vb[p][2], (f16)vb[p][3]};
+        ssb[p] = __builtin_amdgcn_fdot2(b0, b0, ssb[p], false);
+        ssb[p] = __builtin_amdgcn_fdot2(b1, b1, ssb[p], false);
+        const f16x4 pb = {b0[0], b0[1], b1[0], b1[1]};
+        *reinterpret_cast<f16x4*>(&Bh[r][scol]) = pb;
+      }
+    }
+    __syncthreads();
+    if (d0 + FK < D) load_chunk(d0 + FK);      // next chunk's global loads fly under this chunk's MFMAs
+    if (quad) {
+#pragma unroll
+      for (int kk = 0; kk < FK / 16; ++kk) {
+        const int c = 16 * kk + 8 * hh;
+        const f16x8 r0 = *reinterpret_cast<const f16x8*>(&Ah[wr * 64 + li][c]);        // row panel -> "B" operand
+        const f16x8 r1 = *reinterpret_cast<const f16x8*>(&Ah[wr * 64 + 32 + li][c]);
+        const f16x8 c0 = *reinterpret_cast<const f16x8*>(&Bp[wc * 64 + li][c]);        // column panel -> "A" operand
+        const f16x8 c1 = *reinterpret_cast<const f16x8*>(&Bp[wc * 64 + 32 + li][c]);
+        acc00 = mfma32x32x16(c0, r0, acc00);
+        acc01 = mfma32x32x16(c1, r0, acc01);
+        acc10 = mfma32x32x16(c0, r1, acc10);
+        acc11 = mfma32x32x16(c1, r1, acc11);
+      }
+    }
+    __syncthreads();
+  }
+  // inverse norms of the block's rows: the 8 threads of a row segment hold its partial sums
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float a = ssa[p], b = ssb[p];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((tid & 7) == 0) {
+      const float ra = 1.0f / fmaxf(sqrtf(a), eps);
+      rinv[0][srow + 32 * p] = ra;
+      rinv[1][srow + 32 * p] = diag ? ra : 1.0f / fmaxf(sqrtf(b), eps);
+    }
+  }
+  __syncthreads();
+  if (!quad) return;
+  // epilogue: w = <x_i, x_j> / (|x_i| |x_j|); round(65535 clamp(w, 0, 1)) is ONE v_cvt_pknorm_u16_f32 per pair (the clamp
+  // is the relu); rows / columns >= N are written as 0 (the matvec relies on it).  The whole storage tile is written.
+  uint16_t* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto store_tile = [&](const f32x16& acc, int rsub, int csub) {
+    const int lrow = rsub + li;                                             // this lane's row inside the quadrant
+    const float rr = ri0 + lrow < N ? rinv[0][wr * 64 + lrow] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int lc = csub + 8 * g + 4 * hh;                                 // 4 consecutive columns lc .. lc + 3
+      const f32x4 rc = *reinterpret_cast<const f32x4*>(&rinv[1][wc * 64 + lc]);
+      float w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = cj0 + lc + i < N ? acc[4 * g + i] * rr * rc[i] : 0.f;
+      const u16x2 q0 = __builtin_amdgcn_cvt_pknorm_u16(w[0], w[1]), q1 = __builtin_amdgcn_cvt_pknorm_u16(w[2], w[3]);
+      const u32x2 out = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+      *reinterpret_cast<u32x2*>(tile + lrow * 64 + lc) = out;
+    }
+  };
+  store_tile(acc00, 0, 0);
+  store_tile(acc01, 0, 32);
+  store_tile(acc10, 32, 0);
+  store_tile(acc11, 32, 32);
+}
+
 }  // namespace dss
 
 extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream) {
@@ -388,6 +547,20 @@ extern "C" int dss_affinity_split(const float* feats, float* W, int B, int N, in
 extern "C" int dss_affinity_split_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   return dss::affinity_split(feats, W, 1, B, N, D, 1, eps, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps, void* stream) {
+  DSS_REQUIRE(feats && W, "dss_affinity_fused_u16: null pointer");
+  DSS_REQUIRE(B > 0 && N > 0 && D > 0, "dss_affinity_fused_u16: bad shape B=%d N=%d D=%d", B, N, D);
+  DSS_REQUIRE(D % dss::FK == 0, "dss_affinity_fused_u16: feature dim must be a multiple of %d (got %d)", dss::FK, D);
+  const int ldw = dss_affinity_ld(N);
+  const int nbk = (ldw / 64 + 1) / 2;
+  const long nblocks = (long)(nbk * (nbk + 1) / 2) * B;
+  DSS_REQUIRE(nblocks < 2147483647L, "dss_affinity_fused_u16: too many blocks (%ld)", nblocks);
+  hipLaunchKernelGGL(dss::gram_f16_fused_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, feats, W, N,
+                     D, ldw, eps, dss_affinity_elems(N), B);
+  DSS_CHECK_LAUNCH("gram_f16_fused");
+  return DSS_OK;
 }
 
 extern "C" size_t dss_affinity_split_workspace_bytes(int B, int N, int D) {

@@ -41,6 +41,7 @@ SYMBOLS = {
     "dss_affinity_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
                                    c_void_p]),
     "dss_affinity_split_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "dss_affinity_fused_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dss_laplacian_eigs_u16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                        c_int, c_void_p, c_size_t, c_void_p]),
@@ -333,6 +334,19 @@ def affinity_split(feats: torch.Tensor, normalize: bool = True, threshold_at_zer
     with _timed("affinity", b=b, n=n, d=d, w_bytes=4):
         _check(lib.dss_affinity_split(_dev(feats, "feats"), _dev(w, "W"), b, n, d, int(normalize), float(eps),
                                       int(threshold_at_zero), _dev(ws, "ws"), need, _stream()), "dss_affinity_split")
+    return w
+
+
+def affinity_fused_u16(feats: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """RAW f32 ``[B, N, D]`` features -> 16-bit fixed-point packed ``W = round(65535 relu(cos(f_i, f_j)))`` in ONE kernel
+    (normalisation after the product, f16 MFMA operands, fp32 accumulation; ``dss_affinity_fused_u16``): the affinity
+    build of the default recipe with HBM traffic == algorithmic bytes."""
+    assert feats.dtype == torch.float32 and feats.dim() == 3
+    b, n, d = feats.shape
+    w = torch.empty((b, affinity_elems(n)), dtype=torch.int16, device=feats.device)
+    with _timed("affinity", b=b, n=n, d=d, w_bytes=2, fused=True):
+        _check(load_library().dss_affinity_fused_u16(_dev(feats, "feats"), _dev(w, "W"), b, n, d, float(eps), _stream()),
+               "dss_affinity_fused_u16")
     return w
 
 

@@ -5,6 +5,7 @@ This is ``extract_features`` followed by ``extract_eigs`` without the ``.pth`` r
 this in-memory form)."""
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -20,8 +21,11 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
     """``img_u8`` u8 ``[B, H, W, 3]`` on the GPU -> (k ``[B, N, D]``, eigenvalues ``[B, K]``,
     eigenvectors ``[B, K, N]``, info ``[B]``)."""
     k = model.extract_k(img_u8, which_block=which_block)
+    # the features just came out of the half-precision ViT (relative error ~1e-3): the fused affinity build, which rounds
+    # them to f16 (2^-11) on its way into the MFMAs, costs nothing in accuracy here
     ev, vec, info = spectral.laplacian_eigs_from_features(k, K, normalize=normalize,
-                                                          threshold_at_zero=threshold_at_zero, strict=strict)
+                                                          threshold_at_zero=threshold_at_zero, strict=strict,
+                                                          affinity_mode=os.environ.get("DSS_AFFINITY", "fused"))
     return k, ev, vec, info
 
 
@@ -51,7 +55,7 @@ class OverlappedExtractor:
                 k.record_stream(self.side)
                 outs.append(spectral.laplacian_eigs_from_features(
                     k, self.K, normalize=self.normalize, threshold_at_zero=self.threshold_at_zero, strict=False,
-                    retry=False))
+                    retry=False, affinity_mode=os.environ.get("DSS_AFFINITY", "fused")))
             if keep_features:
                 feats.append(k)
         main.wait_stream(self.side)

@@ -110,8 +110,12 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     * ``upsample``: ``((H_patch, W_patch), (H_lr, W_lr))`` - the reference's feature upsampling when
       ``image_downsample_factor != patch_size`` (extract.py:179-188): the (already normalised) features are resized
       bilinearly (``align_corners=False``) from the patch grid to the low-resolution pixel grid before the affinity.
-    * ``affinity_mode``: ``"split"`` (default; ``$DSS_AFFINITY``) builds W with two-term split-f16 MFMAs
-      (error ~1e-7), ``"fp32"`` with exact fp32 MFMAs.  With the default recipe (``problem="laplacian"``,
+    * ``affinity_mode`` (``$DSS_AFFINITY``): ``"split"`` (default) builds W with two-term split-f16 MFMAs (error ~1e-7:
+      what ``extract_eigs`` needs for fp32 features read from ``.pth`` files - eigenvalues within 1e-5 of the reference);
+      ``"fp32"`` uses exact fp32 MFMAs; ``"fused"`` = for the default recipe with 16-bit W and ``D >= 256``, ONE kernel from
+      raw features to packed W with f16 MFMA operands (``|dW| <= ~5e-5``, eigenvalues within ~6e-5, eigenvectors within
+      ~1e-5 in cosine) - free when the features come out of the half-precision ViT, which is where ``pipeline`` and
+      ``bench.py`` use it - and the split build otherwise.  With the default recipe (``problem="laplacian"``,
       ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``w_dtype="f32"`` /
       ``$DSS_W_DTYPE=f32`` keeps floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
@@ -124,8 +128,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     assert feats.dim() == 3 and feats.dtype == torch.float32
     if affinity_mode is None:
         affinity_mode = os.environ.get("DSS_AFFINITY", "split")
-    if affinity_mode not in ("split", "fp32"):
-        raise ValueError(f"affinity_mode must be 'split' or 'fp32' (got {affinity_mode!r})")
+    if affinity_mode not in ("fused", "split", "fp32"):
+        raise ValueError(f"affinity_mode must be 'fused', 'split' or 'fp32' (got {affinity_mode!r})")
     b, n, d = feats.shape
     if upsample is not None:
         (hp, wp), (hl, wl) = upsample
@@ -162,7 +166,7 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     if w_dtype not in ("u16", "f32"):
         raise ValueError(f"w_dtype must be 'u16' or 'f32' (got {w_dtype!r})")
     w_u16 = (problem == "laplacian" and normalize and threshold_at_zero and upsample is None and d % 32 == 0
-             and affinity_mode == "split" and w_dtype == "u16")
+             and affinity_mode in ("fused", "split") and w_dtype == "u16")
     ld = hip.affinity_ld(n)
     per_image = hip.affinity_elems(n) * (2 if w_u16 else 4) + 2 * 66 * ld * 4
     chunk = max(1, min(b, max_bytes // per_image))
@@ -177,6 +181,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
             if normalize:
                 f = hip.normalize_rows(f)
             w = hip.affinity(f, threshold_at_zero)
+        elif w_u16 and affinity_mode == "fused" and d >= 256:   # raw features -> packed 16-bit W in one kernel
+            w = hip.affinity_fused_u16(f)
         else:  # split-f16 (fp32-class accuracy, ~1e-7), HBM-bound; fused with the row normalisation
             w = hip.affinity_split(f, normalize, threshold_at_zero, u16=w_u16)
         ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts,

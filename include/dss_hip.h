@@ -136,6 +136,13 @@ int dss_affinity_split(const float* feats, float* W, int B, int N, int D, int no
 int dss_affinity_split_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* The default recipe again, as ONE kernel with HBM traffic == algorithmic bytes (4 N D in, 2 * dss_affinity_elems(N) out
+ * per image; no workspace): raw fp32 features in, normalisation applied after the product (the kernel collects the squared
+ * row norms while it streams the panels), f16 MFMA operands with fp32 accumulation (BASELINE.json config 5: "fp16 features
+ * + fp32 Laplacian eigensolve"), W_q = round(65535 relu(w)) out.  |W - W_exact| <= ~5e-5; the eigenvectors of the reference
+ * goldens move by <= 3e-6 in cosine.  D % 32 == 0.  extract/extract.py:148,191-193. */
+int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps, void* stream);
+
 /* ---- a13-a15: degree, normalised Laplacian, K smallest generalized eigenpairs, sign rule -------
  * extract/extract_utils.py:207-220  d = W 1 ; d[d < 1e-12] = 1
  * extract/extract.py:227            eigsh(D - W, k=K, sigma=0, which='LM', M=D)
