@@ -27,7 +27,8 @@
 #include "common.h"
 
 // scripts/probes/attn_clock_probe.hip includes this file with DSS_ATTN_CLOCK defined to read the shader clock the chip
-// sustains INSIDE the kernel; in the library the hooks compile to nothing.
+// sustains INSIDE the kernel, scripts/probes/attn_timeline_probe.hip with DSS_ATTN_TIMELINE to record when and where
+// every workgroup ran; in the library the hooks compile to nothing.
 #ifdef DSS_ATTN_CLOCK   // shader clock sustained inside the kernel: s_memtime (shader cycles) vs s_memrealtime (100 MHz)
 __device__ unsigned long long dss_clock_buf[4];
 #define DSS_CLOCK_BEGIN                                                                       \
@@ -38,6 +39,19 @@ __device__ unsigned long long dss_clock_buf[4];
   if (clk_on) {                                                                               \
     dss_clock_buf[0] = __builtin_readcyclecounter() - clk_c0;                                 \
     dss_clock_buf[1] = wall_clock64() - clk_r0;                                               \
+  }
+#elif defined(DSS_ATTN_TIMELINE)   // per-workgroup start / end (100 MHz counter) and placement (HW_ID, XCC_ID)
+__device__ unsigned long long* dss_timeline_buf;   // [gridDim.x][4]
+#define DSS_CLOCK_BEGIN                                                                       \
+  unsigned long long tl_r0 = 0;                                                               \
+  if (threadIdx.x == 0) tl_r0 = wall_clock64();
+#define DSS_CLOCK_END                                                                         \
+  if (threadIdx.x == 0) {                                                                     \
+    unsigned hw, xcc;                                                                         \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                          \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                        \
+    unsigned long long* t = dss_timeline_buf + 4ull * blockIdx.x;                             \
+    t[0] = tl_r0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;                               \
   }
 #else
 #define DSS_CLOCK_BEGIN
@@ -116,8 +130,14 @@ __device__ __forceinline__ float half_pair_sum(float x) {
 //   * the ragged last key tile is peeled out of the main loop (instruction issue is the scarce resource: the main loop
 //     carries no per-half conditions); its keys past the end are masked through the MFMA accumulator's INITIAL value
 //     (-inf in their rows, 0 elsewhere - the MFMA adds it for free).
-// Still on the table (measured gap: the register-only body runs 307 cycles per half per SIMD, the kernel 578): the 12
-// LDS fragment reads, ~10 waitcnts and ~25 scalar/branch instructions per half that the probe body does not have.
+// Where the rest goes (profiles/r02_attention_probes.txt): the register-only body runs 307 cycles per half per SIMD, the
+// kernel 578.  Ablations of this kernel: fragments from registers instead of LDS -4 %, no restaging -4 %, no restaging
+// and no barrier -9 %; the timeline probe shows 1.61 of the 2 workgroup slots of a CU occupied on average - 6.5 us pass
+// between the end of a workgroup (its output stores drain before its registers and LDS are released) and the start of
+// its successor, 16 % of a 40 us workgroup.  Tried against that and measured slower: workgroups that walk several work
+// items (2 / 4 / 8 / all of a CU slot's ~14: +1 ... +20 %; item times vary 23-74 us with what the neighbours are doing, so
+// static walks lose to the hardware dispatcher what they save on the gap), a three-tile LDS ring with the score MFMAs of
+// the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower).
 template <class T>
 __global__ __launch_bounds__(512, 4) void attn_fwd4_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
                                                            int heads, int nb, int nqb, float scale_log2,
