@@ -95,6 +95,33 @@ def synthetic_state_dict(model_name: str, seed: int = 0, ln_jitter: float = 0.0)
     return sd
 
 
+def dino_like_state_dict(model_name: str, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights reshaped to stress what REAL DINO checkpoints stress and plain ``trunc_normal(0.02)`` does not
+    (no checkpoint can be downloaded here): three residual-stream channels that carry activations of ~150-300 from
+    block 2 on (DINO's "massive activations": large fc2 biases on fixed channels), LayerNorm gains that ignore those
+    channels and re-inflate the rest by 20x (what a trained network does about them - without it the outliers crush every
+    other channel and all patches get the same feature), sharpened attention logits (q/k rows x3: peaked softmax rows
+    next to flat ones) and wide GELU inputs (fc1 x4: the erf tails).  Same key set as ``synthetic_state_dict``."""
+    dim, depth, heads, patch = VIT_CONFIGS[model_name.lower()]
+    sd = synthetic_state_dict(model_name, seed, ln_jitter=0.05)
+    rng = np.random.default_rng(seed + 4242)
+    chans = rng.choice(dim, size=3, replace=False)
+    bumps = (150.0, -125.0, 300.0)
+    for i, blk in enumerate((2, 3, 4)):
+        sd[f"blocks.{blk}.mlp.fc2.bias"][chans[i]] += bumps[i]          # residual outliers from here on
+    for i in range(3, depth):
+        for nm in ("norm1", "norm2"):
+            sd[f"blocks.{i}.{nm}.weight"] *= 20.0
+            sd[f"blocks.{i}.{nm}.weight"][chans] = 0.0
+            sd[f"blocks.{i}.{nm}.bias"][chans] = 0.0
+    for i in (1, 5, 9):   # logits x9 at D = 384 (their spread grows with D for random weights: same spread at D = 768):
+        sd[f"blocks.{i}.attn.qkv.weight"][: 2 * dim] *= 3.0 * (384.0 / dim) ** 0.5      # peaked attention rows
+    for i in (3, 8):
+        sd[f"blocks.{i}.mlp.fc1.weight"] *= 4.0                          # GELU inputs out to the erf tails
+        sd[f"blocks.{i}.mlp.fc2.weight"] *= 0.25
+    return sd
+
+
 def synthetic_features(kind: str, n: int, d: int, seed: int, hw: Tuple[int, int] | None = None) -> np.ndarray:
     """f32 ``[n, d]`` features.
 
