@@ -14,10 +14,14 @@ Under ``python -m torch.distributed.run --nproc-per-node N`` every rank takes th
 ``i % world_size == rank`` of the sorted work list (one process per GPU, no collective on the data path).
 
 Scope: ``which_matrix`` in {'laplacian', 'matting_laplacian'} (``lapnorm`` True or False), 'affinity' and
-'affinity_svd', all with ``image_color_lambda == 0`` - the ``extract_eigs`` defaults, the README recipes and the
-reference's other solver branches, including feature upsampling (``image_downsample_factor``).  Colour affinities
-(``image_color_lambda > 0``, pymatting KNN / random-walk) and the dead ``affinity_torch`` branch raise
-``NotImplementedError``.
+'affinity_svd' - the ``extract_eigs`` defaults, the README recipes and the reference's other solver branches, including
+feature upsampling (``image_downsample_factor``) and the colour-affinity fusion (``image_color_lambda > 0`` with
+``which_color_matrix`` 'knn' or 'rw': W_color is built on the GPU, extract_utils.knn_affinity / rw_affinity).  The dead
+``affinity_torch`` branch raises ``NotImplementedError``.
+
+The consumers of the eigen files keep the reference's names and file formats too:
+``extract_single_region_segmentations`` (:383-426), ``extract_multi_region_segmentations`` (:283-377),
+``extract_bboxes`` (:429-495) and ``extract_bbox_features`` (:498-544).
 """
 from __future__ import annotations
 
@@ -193,9 +197,29 @@ def _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsamp
         return which_matrix  # these branches ignore the Laplacian / colour options (extract.py:159-172)
     if which_matrix not in ("laplacian", "matting_laplacian"):
         raise ValueError(f"unknown which_matrix {which_matrix!r}")
-    if image_color_lambda > 0:
-        raise NotImplementedError("image_color_lambda > 0 (KNN / random-walk colour affinities) is not built")
     return "laplacian" if lapnorm else "laplacian_unnormalized"
+
+
+def _color_spec(which_matrix: str, which_color_matrix: str, image_color_lambda: float, images_root: str):
+    """``None`` or ``(lambda, 'knn' | 'rw', images_root)`` for the colour-fusion branch (extract.py:197-218)."""
+    if which_matrix not in ("laplacian", "matting_laplacian") or not image_color_lambda > 0:
+        return None
+    if which_color_matrix not in ("knn", "rw"):
+        # the reference leaves W_lr undefined here and dies with a NameError
+        raise ValueError(f"which_color_matrix must be 'knn' or 'rw' (got {which_color_matrix!r})")
+    return float(image_color_lambda), which_color_matrix, images_root
+
+
+def _color_affinity(color, image_id: str, lr: Tuple[int, int], device: torch.device) -> torch.Tensor:
+    """extract.py:201-213: the image, resized (PIL bilinear, like there) to the grid the features live on, -> dense
+    ``W_color [N, N]`` f32 on the device."""
+    import numpy as np
+    from PIL import Image
+
+    _, which, images_root = color
+    image_lr = Image.open(str(Path(images_root) / f"{image_id}.jpg")).convert("RGB").resize((lr[1], lr[0]), Image.BILINEAR)
+    image_lr = torch.from_numpy(np.array(image_lr) / 255.0).to(device)
+    return utils.knn_affinity(image_lr) if which == "knn" else utils.rw_affinity(image_lr)
 
 
 def _load_features(features_file: str, which_features: str) -> Tuple[dict, torch.Tensor]:
@@ -216,16 +240,36 @@ def _upsample_spec(data_dict: dict, which_matrix: str, image_downsample_factor: 
     return None if lr == (h_patch, w_patch) else ((h_patch, w_patch), lr)
 
 
+def _lr_grid(data_dict: dict, image_downsample_factor: Optional[int]) -> Tuple[int, int]:
+    """(H_pad_lr, W_pad_lr) of extract.py:178-181: the grid the Laplacian branches put the affinity on."""
+    _, _, _, _, p, _, _, h_pad, w_pad = utils.get_image_sizes(data_dict)
+    f = p if image_downsample_factor is None else image_downsample_factor
+    return h_pad // f, w_pad // f
+
+
 def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: bool, threshold_at_zero: bool,
                    device: torch.device, saver: Optional["_AsyncSaver"] = None, problem: str = "laplacian",
-                   upsample=None):
+                   upsample=None, color=None, color_items: Optional[List[Tuple[str, Tuple[int, int]]]] = None):
     feats = torch.stack([f for _, f in items]).to(device, non_blocking=True)
-    # strict=False: the reference never aborts a run over one image (bare except -> second solve, extract.py:228-229).
-    # laplacian_eigs_from_features re-solves a starved image with a larger Krylov space and, failing that, densely;
-    # anything still flagged is saved as it is and reported here.
-    ev, vec, info = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
-                                                          threshold_at_zero=threshold_at_zero, problem=problem,
-                                                          upsample=upsample, strict=False)
+    if color is not None:
+        # extract.py:191-218 with a colour term: W_comb = W_feat / max(W_feat) + lambda * W_color, dense on the device
+        # (the matrix is no longer a Gram matrix of the features), packed into the solver's tile layout, same kernel.
+        chunks = []
+        per = max(1, (4 << 30) // (4 * (feats.shape[1] if upsample is None else upsample[1][0] * upsample[1][1]) ** 2))
+        for s in range(0, len(items), per):
+            w = spectral.feature_affinity_dense(feats[s:s + per], normalize, threshold_at_zero, upsample)
+            for j, (image_id, lr) in enumerate(color_items[s:s + per]):
+                w[j] += color[0] * _color_affinity(color, image_id, lr, device)
+            chunks.append(spectral.eigs_from_dense_affinity(w, K, problem))
+            del w
+        ev, vec, info = (torch.cat([c[i] for c in chunks]) for i in range(3))
+    else:
+        # strict=False: the reference never aborts a run over one image (bare except -> second solve,
+        # extract.py:228-229).  laplacian_eigs_from_features re-solves a starved image with a larger Krylov space and,
+        # failing that, densely; anything still flagged is saved as it is and reported here.
+        ev, vec, info = spectral.laplacian_eigs_from_features(feats, K, normalize=normalize,
+                                                              threshold_at_zero=threshold_at_zero, problem=problem,
+                                                              upsample=upsample, strict=False)
     bad = (info <= 0).nonzero().flatten().tolist()
     if bad:
         print(f"[dss] WARNING: eigensolver did not converge for {[items[j][0] for j in bad]} (saved as is)")
@@ -257,8 +301,10 @@ def _extract_eig(inp: Tuple[int, str], K: int, images_root: str, output_dir: str
     problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
                                  data_dict["patch_size"])
     utils.get_image_sizes(data_dict)  # keeps the reference's B == 1 assertion
+    color = _color_spec(which_matrix, which_color_matrix, image_color_lambda, images_root)
     _run_eig_batch([(output_file, feats)], K, normalize, threshold_at_zero, local_device(), problem=problem,
-                   upsample=_upsample_spec(data_dict, which_matrix, image_downsample_factor))
+                   upsample=_upsample_spec(data_dict, which_matrix, image_downsample_factor), color=color,
+                   color_items=[(image_id, _lr_grid(data_dict, image_downsample_factor))])
 
 
 def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_matrix: str = "laplacian",
@@ -285,8 +331,15 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         data_dict, feats = _load_features(str(f), which_features)
         return data_dict, feats
 
+    color = _color_spec(which_matrix, which_color_matrix, image_color_lambda, images_root)
     pending: Dict[Tuple, List[Tuple[str, torch.Tensor]]] = {}
+    pending_ids: Dict[Tuple, List[Tuple[str, Tuple[int, int]]]] = {}
     problems: Dict[Tuple, str] = {}
+
+    def run(key):
+        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1], color,
+                       pending_ids.pop(key))
+
     bs = max(1, int(batch_size))
     n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
     saver = _AsyncSaver()
@@ -303,15 +356,16 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
             key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
             pending.setdefault(key, []).append((output_file, feats))
+            pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
             problems[key] = problem
             n_pending += 1
             if len(pending[key]) < bs and n_pending >= max_pending:
                 key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
             if len(pending[key]) >= bs or n_pending >= max_pending:
                 n_pending -= len(pending[key])
-                _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1])
+                run(key)
     for key in list(pending):
-        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1])
+        run(key)
     saver.close()
     _barrier()
 
@@ -344,9 +398,139 @@ def extract_single_region_segmentations(features_dir: str, eigs_dir: str, output
     utils.parallel_process(utils.get_paired_input_files(features_dir, eigs_dir), fn, multiprocessing)
 
 
+def _extract_multi_region_segmentations(inp: Tuple[int, Tuple[str, str]], adaptive: bool, non_adaptive_num_segments: int,
+                                        infer_bg_index: bool, kmeans_baseline: bool, output_dir: str,
+                                        num_eigenvectors: int):
+    """One (feature file, eigen file) pair -> one label PNG (reference extract/extract.py:283-352): K-means over the
+    non-constant eigenvectors (or, ``kmeans_baseline``, over the raw features); ``adaptive`` picks the number of segments
+    from the largest eigengap; ``infer_bg_index`` renames the segment owning most of the border to 0.  Host-side: the
+    clustering is ``sklearn.cluster.KMeans`` exactly as in the reference (N <= a few thousand points in <= K - 1
+    dimensions), so that a seeded run reproduces the reference's labels."""
+    import numpy as np
+    from PIL import Image
+    from sklearn.cluster import KMeans
+
+    index, (feature_path, eigs_path) = inp
+    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
+    data_dict.update(torch.load(eigs_path, map_location="cpu", weights_only=False))
+    output_file = str(Path(output_dir) / f"{Path(data_dict['id'])}.png")
+    if Path(output_file).is_file():
+        print(f"Skipping existing file {str(output_file)}")
+        return
+    sizes = utils.get_image_sizes(data_dict)
+    h_patch, w_patch = sizes[5], sizes[6]
+    if adaptive:   # the largest eigengap, not counting the one after eigenvalue 0
+        indices_by_gap = np.argsort(np.diff(data_dict["eigenvalues"].numpy()))[::-1]
+        n_clusters = int(indices_by_gap[indices_by_gap != 0][0]) + 1
+    else:
+        n_clusters = non_adaptive_num_segments
+    kmeans = KMeans(n_clusters=n_clusters)
+    if kmeans_baseline:
+        clusters = kmeans.fit_predict(data_dict["k"].squeeze().numpy())
+    else:
+        clusters = kmeans.fit_predict(data_dict["eigenvectors"][1:1 + num_eigenvectors].numpy().T)
+    if clusters.size == h_patch * w_patch:
+        segmap = clusters.reshape(h_patch, w_patch)
+    elif clusters.size == h_patch * w_patch * 4:   # eigenvectors computed on the 2x upsampled grid
+        segmap = clusters.reshape(h_patch * 2, w_patch * 2)
+    else:
+        raise ValueError()
+    if infer_bg_index:   # swap labels: the segment with the most border pixels becomes 0
+        indices, normalized_counts = utils.get_border_fraction(segmap)
+        bg_index = indices[np.argmax(normalized_counts)].item()
+        bg_region, zero_region = (segmap == bg_index), (segmap == 0)
+        segmap[bg_region] = 0
+        segmap[zero_region] = bg_index
+    Image.fromarray(segmap).convert("L").save(output_file)
+
+
+def extract_multi_region_segmentations(features_dir: str, eigs_dir: str, output_dir: str, adaptive: bool = False,
+                                       non_adaptive_num_segments: int = 4, infer_bg_index: bool = True,
+                                       kmeans_baseline: bool = False, num_eigenvectors: int = 1_000_000,
+                                       multiprocessing: int = 0):
+    """python extract.py extract_multi_region_segmentations --features_dir F --eigs_dir E --output_dir O"""
+    utils.make_output_dir(output_dir)
+    fn = partial(_extract_multi_region_segmentations, adaptive=adaptive, infer_bg_index=infer_bg_index,
+                 non_adaptive_num_segments=non_adaptive_num_segments, num_eigenvectors=num_eigenvectors,
+                 kmeans_baseline=kmeans_baseline, output_dir=output_dir)
+    utils.parallel_process(utils.get_paired_input_files(features_dir, eigs_dir), fn, multiprocessing)
+
+
+def _extract_bbox(inp: Tuple[int, Tuple[str, str]], num_erode: int, num_dilate: int, skip_bg_index: bool,
+                  downsample_factor: Optional[int] = None) -> dict:
+    """One (feature file, segmentation PNG) pair -> the boxes of its segments (reference extract/extract.py:429-470):
+    every label (0 = background skipped unless asked) is eroded ``num_erode`` times, dilated ``num_dilate`` times, and
+    boxed ``(xmin, ymin, xmax, ymax)`` with exclusive maxima, in segmentation-grid units and times ``P`` in pixels."""
+    import numpy as np
+    from PIL import Image
+
+    index, (feature_path, segmentation_path) = inp
+    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
+    segmap = np.array(Image.open(str(segmentation_path)))
+    p = utils.get_image_sizes(data_dict, downsample_factor)[4]
+    outputs = {"bboxes": [], "bboxes_original_resolution": [], "segment_indices": [], "id": data_dict["id"],
+               "format": "(xmin, ymin, xmax, ymax)"}
+    for segment_index in sorted(np.unique(segmap).tolist()):
+        if skip_bg_index and not segment_index > 0:
+            continue
+        binary_mask = utils.erode_or_dilate_mask(segmap == segment_index, r=num_erode, erode=True)
+        binary_mask = utils.erode_or_dilate_mask(binary_mask, r=num_dilate, erode=False)
+        ys, xs = np.where(binary_mask == 1)
+        bbox = [int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1]
+        outputs["segment_indices"].append(segment_index)
+        outputs["bboxes"].append(bbox)
+        outputs["bboxes_original_resolution"].append([v * p for v in bbox])
+    return outputs
+
+
+def extract_bboxes(features_dir: str, segmentations_dir: str, output_file: str, num_erode: int = 2, num_dilate: int = 3,
+                   skip_bg_index: bool = True, downsample_factor: Optional[int] = None):
+    """python extract.py extract_bboxes --features_dir F --segmentations_dir S --num_erode 2 --num_dilate 5
+    --output_file bboxes.pth   (one list of per-image dicts in ONE file, reference extract/extract.py:473-495)"""
+    utils.make_output_dir(str(Path(output_file).parent), check_if_empty=False)
+    fn = partial(_extract_bbox, num_erode=num_erode, num_dilate=num_dilate, skip_bg_index=skip_bg_index,
+                 downsample_factor=downsample_factor)
+    all_outputs = [fn(inp) for inp in utils.get_paired_input_files(features_dir, segmentations_dir)]
+    torch.save(all_outputs, output_file)
+    print("Done")
+
+
+def extract_bbox_features(images_root: str, bbox_file: str, model_name: str, output_file: str,
+                          weights: Optional[str] = None, dtype: str = "float16",
+                          synthetic_weights: Optional[int] = None):
+    """python extract.py extract_bbox_features --model_name dino_vits16 --images_root I --bbox_file bboxes.pth
+    --output_file bbox_features.pth   (reference extract/extract.py:498-544): the ViT's CLS output (all blocks + final
+    LayerNorm, ``DinoViT.forward_cls``) of every box crop, stacked per image under ``'features'``.  Crops of equal size
+    inside an image share one forward."""
+    import numpy as np
+    from PIL import Image
+
+    bbox_list = torch.load(bbox_file, weights_only=False)
+    total_num_boxes = sum(len(d["bboxes"]) for d in bbox_list)
+    print(f"Loaded bounding box list. There are {total_num_boxes} total bounding boxes.")
+    device = local_device()
+    model, _, _, _ = utils.get_model(model_name.lower(), device=device, dtype=_DTYPES[str(dtype).lower()],
+                                     weights=weights, synthetic_seed=synthetic_weights)
+    for bbox_dict in bbox_list:
+        image_filename = str(Path(images_root) / f"{bbox_dict['id']}.jpg")
+        image = torch.from_numpy(np.asarray(Image.open(image_filename).convert("RGB")).copy()).to(device)  # [H, W, 3] u8
+        boxes = [tuple(int(v) for v in box) for box in bbox_dict["bboxes_original_resolution"]]
+        feats: List[Optional[torch.Tensor]] = [None] * len(boxes)
+        for group in spectral.group_by_shape([(b[3] - b[1], b[2] - b[0]) for b in boxes], 64):
+            crops = torch.stack([image[boxes[j][1]:boxes[j][3], boxes[j][0]:boxes[j][2]] for j in group])
+            out = model.forward_cls(crops).cpu()
+            for j, f in zip(group, out):
+                feats[j] = f
+        bbox_dict["features"] = torch.stack(feats, dim=0)   # raises on an image without boxes, as the reference does
+    torch.save(bbox_list, output_file)
+    print(f"Saved features to {output_file}")
+
+
 # ------------------------------------------------------------------------------------------ CLI
 COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs,
-                extract_single_region_segmentations=extract_single_region_segmentations)
+                extract_single_region_segmentations=extract_single_region_segmentations,
+                extract_multi_region_segmentations=extract_multi_region_segmentations,
+                extract_bboxes=extract_bboxes, extract_bbox_features=extract_bbox_features)
 
 
 def _literal(s: str):

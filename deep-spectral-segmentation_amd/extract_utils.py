@@ -2,7 +2,9 @@
 ``extract/extract_utils.py`` for the symbols the hot path uses:
 
   ImagesDataset (:17-37), get_model (:40-50), get_transform (:53-59), get_image_sizes (:73-79),
-  make_output_dir (:98-104), parallel_process (:138-148), get_diagonal (:207-220).
+  make_output_dir (:98-104), parallel_process (:138-148), get_diagonal (:207-220),
+and for the consumers / options either side of it: get_largest_cc (:107-112),
+erode_or_dilate_mask (:115-121), get_border_fraction (:124-135), knn_affinity (:150-189), rw_affinity (:192-204).
 
 Differences that are deliberate and documented in DESIGN.md:
   * images are decoded with PIL (cv2 / torchvision are not part of this stack) and stay uint8 HWC: the
@@ -178,3 +180,101 @@ def get_diagonal(W: torch.Tensor, n: Optional[int] = None, threshold: float = 1e
     d = W[:n, :n].sum(dim=1)
     d[d < threshold] = 1.0
     return d
+
+
+# ------------------------------------------------------------------------- consumers of the eigen files
+def get_largest_cc(mask: np.ndarray) -> np.ndarray:
+    """Largest connected component of a boolean mask (reference extract_utils.py:107-112, ``skimage.measure.label``
+    with its default full connectivity - 8-connected in 2-D - restated with ``scipy.ndimage.label``; skimage is not part
+    of this stack).  Ties go to the component met first in raster order, as ``argmax(bincount)`` does there."""
+    from scipy import ndimage
+
+    mask = np.asarray(mask)
+    labels, count = ndimage.label(mask, structure=np.ones((3,) * mask.ndim, dtype=bool))
+    if count == 0:   # the reference raises on an empty mask (argmax of an empty sequence)
+        raise ValueError("attempt to get argmax of an empty sequence")
+    return labels == (np.argmax(np.bincount(labels.ravel())[1:]) + 1)
+
+
+def erode_or_dilate_mask(x, r: int = 0, erode: bool = True):
+    """``r`` rounds of binary erosion (or dilation) that never erase the whole mask (reference extract_utils.py:115-121).
+    ``skimage.morphology.binary_erosion / binary_dilation`` with their default footprint (the 4-connected cross) are
+    ``scipy.ndimage``'s with ``border_value=True`` for the erosion (pixels outside the image count as set) and ``False``
+    for the dilation."""
+    from scipy import ndimage
+
+    x = np.asarray(x)
+    for _ in range(r):
+        x_new = (ndimage.binary_erosion(x, border_value=True) if erode else ndimage.binary_dilation(x))
+        if x_new.sum() > 0:  # do not erode the entire mask away
+            x = x_new
+    return x
+
+
+def get_border_fraction(segmap: np.ndarray):
+    """``(labels, fraction of the 2 (H + W) border pixels carrying each label)`` - corner pixels count twice, labels in
+    ascending order (reference extract_utils.py:124-135)."""
+    border = np.concatenate([segmap[:, 0], segmap[:, -1], segmap[0, :], segmap[-1, :]])
+    indices = np.unique(segmap)
+    counts = np.array([(border == i).sum() for i in indices])
+    return indices, counts / (2 * (segmap.shape[0] + segmap.shape[1]))
+
+
+@torch.no_grad()
+def knn_affinity(image: torch.Tensor, n_neighbors=(20, 10), distance_weights=(2.0, 0.1)) -> torch.Tensor:
+    """KNN colour affinity (reference extract_utils.py:150-189) built ON THE GPU: ``image`` = ``[H, W, 3]`` in [0, 1] on
+    the device; returns the DENSE symmetric ``[H W, H W]`` f32 matrix the reference reaches with ``W_lr.todense()``.
+    For each (k, distance_weight): every pixel is linked to its k nearest neighbours (itself included, as in pymatting's
+    ``knn(f, f, k)``) in the 5-D space ``(r, g, b, dw x, dw y)``, ``x, y`` in [0, 1]; an entry counts how many times the
+    pair was linked, from either side, over both scales (``csr_matrix`` sums duplicates; the diagonal is therefore 4).
+    pymatting's kd-tree is replaced by exhaustive search over the same float32 points with fp64 distances (what an exact
+    kd-tree such as scipy's cKDTree computes).  On 8-bit colours and a regular grid EXACT ties at the k-th place are
+    common (5-50 pixels of a 14 x 14 image); a kd-tree resolves them by traversal order, which cannot be reproduced
+    without pymatting itself - here the lower pixel index wins (stable sort).  MEASURED: swapping the tied neighbours moves
+    the eigenvalues of the fused Laplacian by ~3e-4 - that is the reference's own implementation dependence, not noise of
+    this builder (tests/test_consumers.py pins everything else against the reference run with the same tie rule)."""
+    h, w = image.shape[:2]
+    n = h * w
+    dev = image.device
+    rgb = image.reshape(n, 3).to(torch.float64)
+    x = torch.linspace(0, 1, w, dtype=torch.float64, device=dev).repeat(h)
+    y = torch.linspace(0, 1, h, dtype=torch.float64, device=dev).repeat_interleave(w)
+    out = torch.zeros((n, n), dtype=torch.float32, device=dev)
+    rows = max(1, min(n, (512 << 20) // (8 * n)))   # <= 512 MiB of distances at a time
+    for k, dw in zip(n_neighbors, distance_weights):
+        if k > n:
+            raise ValueError(f"knn_affinity: k={k} neighbours asked of {n} pixels")
+        f = torch.cat([rgb, (dw * x)[:, None], (dw * y)[:, None]], dim=1).to(torch.float32).to(torch.float64)
+        for s in range(0, n, rows):
+            q = f[s:s + rows]
+            d2 = torch.zeros((q.shape[0], n), dtype=torch.float64, device=dev)
+            for c in range(5):
+                d2 += (q[:, c, None] - f[None, :, c]) ** 2
+            nb = d2.sort(dim=1, stable=True).indices[:, :k]
+            i = torch.arange(s, s + q.shape[0], device=dev)[:, None].expand_as(nb)
+            ones = torch.ones(nb.numel(), dtype=torch.float32, device=dev)
+            out.index_put_((i.reshape(-1), nb.reshape(-1)), ones, accumulate=True)
+            out.index_put_((nb.reshape(-1), i.reshape(-1)), ones, accumulate=True)
+    return out
+
+
+@torch.no_grad()
+def rw_affinity(image: torch.Tensor, sigma: float = 0.033, radius: int = 1) -> torch.Tensor:
+    """Random-walk colour affinity (reference extract_utils.py:192-204) on the GPU, dense ``[H W, H W]`` f32.
+    pymatting's ``_rw_laplacian`` is absent from this image and from /root/reference: restated from its documented
+    definition (Grady et al. 2005, eq. 4) - every pixel is linked to the ``(2 r + 1)^2`` window around it, coordinates
+    clamped to the image (so border pixels link to themselves / to a neighbour more than once and the duplicates add up),
+    with weight ``exp(-|I_i - I_j|^2 / sigma^2)``.  UNPINNED against pymatting itself."""
+    h, w = image.shape[:2]
+    n = h * w
+    dev = image.device
+    img = image.to(torch.float64)
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    i = (xs + ys * w).reshape(-1)
+    out = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    for dy in range(-radius, radius + 1):
+        for dx in range(-radius, radius + 1):
+            y2, x2 = (ys + dy).clamp(0, h - 1), (xs + dx).clamp(0, w - 1)
+            wij = torch.exp(-((img - img[y2, x2]) ** 2).sum(-1) / (sigma * sigma)).reshape(-1)
+            out.index_put_((i, (x2 + y2 * w).reshape(-1)), wij, accumulate=True)
+    return out.to(torch.float32)

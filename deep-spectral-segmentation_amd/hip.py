@@ -299,6 +299,21 @@ def affinity_to_dense(wp: torch.Tensor, n: int) -> torch.Tensor:
     return dense
 
 
+def affinity_from_dense(w: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``affinity_to_dense``: dense symmetric f32 ``[B, N, N]`` -> packed f32 ``[B, affinity_elems(N)]`` (rows
+    and columns beyond N zero-filled, as the affinity kernels leave them).  For affinities that are not a feature Gram
+    matrix - the colour-fused ``W_feat + lambda W_color`` of extract.py:199-218 - built densely on the device."""
+    assert w.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == w.shape[2]
+    b, n, _ = w.shape
+    ld = affinity_ld(n)
+    nt = ld // 64
+    full = torch.zeros((b, ld, ld), dtype=torch.float32, device=w.device)
+    full[:, :n, :n] = w
+    tiles = full.view(b, nt, 64, nt, 64).permute(0, 1, 3, 2, 4)            # [B, ti, tj, 64, 64]
+    ti, tj = torch.triu_indices(nt, nt, device=w.device)                   # row-major over i <= j: the packed order
+    return tiles[:, ti, tj].reshape(b, -1).contiguous()
+
+
 def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tensor:
     """f32 ``[B, N, D]`` -> f32 ``[B, affinity_elems(N)]``: ``W = relu(F F^T)`` as packed upper-triangular 64x64
     tiles (layout: include/dss_hip.h)."""

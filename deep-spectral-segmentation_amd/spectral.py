@@ -39,6 +39,22 @@ def _reference_order(problem: str, ev: torch.Tensor, vec: torch.Tensor):
 MAX_LANCZOS_K = 62   # dss_symmetric_eigs: Krylov dimension <= 64 and ncv >= K + 2 (csrc/eigs_core.h EIGS_MAX_NCV)
 
 
+def _dense_eigs_w(w: torch.Tensor, K: int, problem: str):
+    """fp64 dense solve of one symmetric ``[N, N]`` affinity: pairs in the kernel's ranking order."""
+    if problem in ("affinity", "affinity_svd"):
+        th, u = torch.linalg.eigh(w)
+        order = th.abs().argsort(descending=True)[:K]
+        return th[order], u[:, order].T
+    d = w.sum(1)
+    d = torch.where(d < 1e-12, torch.ones_like(d), d)
+    if problem == "laplacian":
+        dis = d.rsqrt()
+        th, u = torch.linalg.eigh(w * dis[:, None] * dis[None, :])
+        return (1.0 - th).flip(0)[:K], (u * dis[:, None]).T.flip(0)[:K]
+    lam, u = torch.linalg.eigh(torch.diag(d) - w)
+    return lam[:K], u[:, :K].T
+
+
 @torch.no_grad()
 def dense_eigs(feats: torch.Tensor, K: int, normalize: bool, threshold_at_zero: bool, problem: str):
     """Exceptional path, never the hot one: the same eigenproblems solved densely in fp64 on the GPU
@@ -54,20 +70,7 @@ def dense_eigs(feats: torch.Tensor, K: int, normalize: bool, threshold_at_zero: 
         w = x @ x.T
         if threshold_at_zero:
             w = w.clamp_min(0)
-        if problem in ("affinity", "affinity_svd"):
-            th, u = torch.linalg.eigh(w)
-            order = th.abs().argsort(descending=True)[:K]
-            ev, v = th[order], u[:, order].T
-        else:
-            d = w.sum(1)
-            d = torch.where(d < 1e-12, torch.ones_like(d), d)
-            if problem == "laplacian":
-                dis = d.rsqrt()
-                th, u = torch.linalg.eigh(w * dis[:, None] * dis[None, :])
-                ev, v = (1.0 - th).flip(0)[:K], (u * dis[:, None]).T.flip(0)[:K]
-            else:
-                lam, u = torch.linalg.eigh(torch.diag(d) - w)
-                ev, v = lam[:K], u[:, :K].T
+        ev, v = _dense_eigs_w(w, K, problem)
         evs.append(ev.float())
         vecs.append(v.float().contiguous())
     ev, vec = torch.stack(evs), torch.stack(vecs).contiguous()
@@ -216,6 +219,67 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
         bad = (info <= 0).nonzero().flatten().tolist()
         if bad:
             raise EigsNotConverged(f"Lanczos did not converge for images {bad[:8]} (info={info[bad[:8]].tolist()})")
+    return ev, vec, info
+
+
+@torch.no_grad()
+def feature_affinity_dense(feats: torch.Tensor, normalize: bool = True, threshold_at_zero: bool = True,
+                           upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None) -> torch.Tensor:
+    """extract.py:146-148,178-194 as a DENSE matrix on the device: ``W_feat = F F^T`` (rows normalised, resized to the
+    low-resolution grid when ``upsample`` says so, thresholded at zero) divided by its maximum - ``[B, N, N]`` f32.
+    Only the colour-fusion branch (``image_color_lambda > 0``) needs the matrix in this form; the default path keeps the
+    packed tiles and never divides."""
+    if feats.dim() == 2:
+        feats = feats[None]
+    b, n, d = feats.shape
+    f = feats.contiguous()
+    if normalize:
+        f = hip.normalize_rows(f)
+    if upsample is not None:
+        (hp, wp), (hl, wl) = upsample
+        f = torch.nn.functional.interpolate(f.transpose(1, 2).reshape(b, d, hp, wp), size=(hl, wl), mode="bilinear",
+                                            align_corners=False)
+        f = f.reshape(b, d, hl * wl).transpose(1, 2).contiguous()
+        n = hl * wl
+    wp_ = hip.affinity_split(f, False, threshold_at_zero) if d % 32 == 0 else hip.affinity(f, threshold_at_zero)
+    w = hip.affinity_to_dense(wp_, n)[:, :n, :n]
+    return w / w.amax(dim=(1, 2), keepdim=True)
+
+
+@torch.no_grad()
+def eigs_from_dense_affinity(w: torch.Tensor, K: int, problem: str = "laplacian", ncv: int = 0, tol: float = 0.0,
+                             max_restarts: int = 0):
+    """Eigenpairs of a general dense symmetric non-negative affinity ``[B, N, N]`` f32 (on the device) with the same
+    Lanczos kernel as the hot path: ``(D - W) v = lambda D v`` (``problem="laplacian"``) or ``(D - W) v = lambda v``
+    (``"laplacian_unnormalized"``), ``D = diag(row sums, < 1e-12 -> 1)``.  The body of extract.py:218-240 for a
+    ``W_comb`` that is not a feature Gram matrix.  Returns ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``;
+    an image that exhausts its restart budget is re-solved with the largest Krylov space and then densely in fp64."""
+    if problem not in ("laplacian", "laplacian_unnormalized"):
+        raise ValueError(f"eigs_from_dense_affinity: unsupported problem {problem!r}")
+    if w.dim() == 2:
+        w = w[None]
+    b, n, _ = w.shape
+    if not K < n:
+        raise ValueError(f"need K < N (K={K}, N={n})")
+    info = torch.zeros(b, dtype=torch.int32, device=w.device)
+    if K > MAX_LANCZOS_K and n > K + 2:
+        ev = torch.empty((b, K), dtype=torch.float32, device=w.device)
+        vec = torch.empty((b, K, n), dtype=torch.float32, device=w.device)
+    else:
+        wp = hip.affinity_from_dense(w)
+        ev, vec, info = hip.laplacian_eigs(wp, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts,
+                                           mode=_PROBLEM_MODE[problem])
+        bad = (info <= 0).nonzero().flatten()
+        if bad.numel():
+            print(f"[dss] {bad.numel()} of {b} images exhausted the Lanczos restart budget: re-solving with ncv=64")
+            ev[bad], vec[bad], info[bad] = hip.laplacian_eigs(
+                wp[bad].contiguous(), n, K, ncv=64, tol=tol, max_restarts=10 * (max_restarts if max_restarts > 0 else 60),
+                mode=_PROBLEM_MODE[problem])
+    for j in (info <= 0).nonzero().flatten().tolist():   # K > 62, or still unconverged: dense fp64, always an answer
+        e, v = _dense_eigs_w(w[j].double(), K, problem)
+        ev[j], vec[j] = e.float(), v.float()
+        hip.sign_rule_(vec[j:j + 1])
+        info[j] = max(1, abs(int(info[j])))
     return ev, vec, info
 
 

@@ -147,6 +147,9 @@ class DinoViT:
                 fc1_w=lp(sd[p + "mlp.fc1.weight"]), fc1_b=lp(sd[p + "mlp.fc1.bias"]),
                 fc2_w=lp(sd[p + "mlp.fc2.weight"]), fc2_b=lp(sd[p + "mlp.fc2.bias"]),
             ))
+        # final LayerNorm: only the CLS-token path (`forward_cls`, extract_bbox_features) needs it
+        self.norm_w = f32(sd["norm.weight"]) if "norm.weight" in sd else None
+        self.norm_b = f32(sd["norm.bias"]) if "norm.bias" in sd else None
         self.scale = 64 ** -0.5
         assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
         self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -164,20 +167,14 @@ class DinoViT:
         return self._pos_cache[key]
 
     @torch.no_grad()
-    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1) -> torch.Tensor:
-        """``img_u8``: u8 ``[B, H, W, 3]`` RGB on the GPU (uncropped).  Returns the hooked K features
-        ``[B, N, D]`` fp32, ``N = (H//P)*(W//P)``, rows in row-major patch order, CLS removed."""
-        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+    def _run_blocks(self, img_u8: torch.Tensor, nblocks: int):
+        """Transform + patch embedding + position encoding, then blocks ``0 .. nblocks-1`` in full.  Returns the fp32
+        residual stream ``x [B, T, D]`` and the last branch output not yet added to it (``pending``, fused into the
+        next LayerNorm by the caller; ``None`` if ``nblocks == 0``)."""
         b, h, w, _ = img_u8.shape
         p, d, heads = self.patch_size, self.embed_dim, self.num_heads
         hp, wp = h // p, w // p
-        if hp == 0 or wp == 0:
-            raise ValueError(f"image {h}x{w} is smaller than one {p}x{p} patch")
-        n, t = hp * wp, hp * wp + 1
-        wb = which_block if which_block >= 0 else self.depth + which_block
-        if not 0 <= wb < self.depth:
-            raise IndexError(f"which_block={which_block} out of range for depth {self.depth}")
-
+        t = hp * wp + 1
         patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
         tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
         cls_row, pos = self._pos(hp * p, wp * p)
@@ -193,7 +190,7 @@ class DinoViT:
         k384 = self.linear_k384 and d == 384
         kres_fc1 = self.gelu == "erf" and ((self.linear_k384 >= 2 and d == 384) or
                                            (self.linear_k384 >= 3 and d in hip.LINEAR_KRES_WIDTHS))
-        for i in range(wb):
+        for i in range(nblocks):
             blk = self.blocks[i]
             hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             if k384:
@@ -220,6 +217,38 @@ class DinoViT:
                 f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),
                                              use_gelu=True).view(b, t, -1)
             pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
+        return x, pending
+
+    @torch.no_grad()
+    def forward_cls(self, img_u8: torch.Tensor) -> torch.Tensor:
+        """DINO's ``model(x)``: all blocks, final LayerNorm, CLS token - ``[B, D]`` fp32.  What the reference's
+        ``extract_bbox_features`` (extract/extract.py:500-544) evaluates on every box crop.  ``img_u8``: u8 ``[B, H, W, 3]``
+        (cropped to whole patches like every other input)."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+        if self.norm_w is None:
+            raise KeyError("state_dict has no final norm.weight / norm.bias: forward_cls needs them")
+        if img_u8.shape[1] < self.patch_size or img_u8.shape[2] < self.patch_size:
+            raise ValueError(f"image {tuple(img_u8.shape[1:3])} is smaller than one {self.patch_size}x{self.patch_size} patch")
+        x, pending = self._run_blocks(img_u8, self.depth)
+        cls = x[:, 0] + pending[:, 0].float()   # the Mlp branch output is row-major [B, T, D] on every path
+        return F.layer_norm(cls, (self.embed_dim,), self.norm_w, self.norm_b, LN_EPS)
+
+    @torch.no_grad()
+    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1) -> torch.Tensor:
+        """``img_u8``: u8 ``[B, H, W, 3]`` RGB on the GPU (uncropped).  Returns the hooked K features
+        ``[B, N, D]`` fp32, ``N = (H//P)*(W//P)``, rows in row-major patch order, CLS removed."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+        b, h, w, _ = img_u8.shape
+        p, d, heads = self.patch_size, self.embed_dim, self.num_heads
+        hp, wp = h // p, w // p
+        if hp == 0 or wp == 0:
+            raise ValueError(f"image {h}x{w} is smaller than one {p}x{p} patch")
+        n, t = hp * wp, hp * wp + 1
+        wb = which_block if which_block >= 0 else self.depth + which_block
+        if not 0 <= wb < self.depth:
+            raise IndexError(f"which_block={which_block} out of range for depth {self.depth}")
+
+        x, pending = self._run_blocks(img_u8, wb)
         blk = self.blocks[wb]
         if self.k_proj_fp32:  # all-fp32 K projection (3x slower GEMM; same operand rounding as nowhere else)
             h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)

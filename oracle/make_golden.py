@@ -413,6 +413,266 @@ def make_single_region_golden(ref):
     print(f"[golden] single_region: png {png.shape} {png.dtype} values {np.unique(png)}")
 
 
+# --------------------------------------------------------------------------- consumers of the eigen files (§8f)
+def _ndimage_morphology():
+    """Stand-ins for ``skimage.morphology.binary_erosion / binary_dilation`` (skimage is not installed): their published
+    definition - scipy.ndimage's operators with the default cross footprint, ``border_value=True`` for the erosion."""
+    from scipy import ndimage
+
+    return (lambda x: ndimage.binary_erosion(x, border_value=True)), (lambda x: ndimage.binary_dilation(x))
+
+
+def _install_skimage_label():
+    """``skimage.measure.label`` stand-in (default = full connectivity)."""
+    from scipy import ndimage
+
+    m = types.ModuleType("skimage.measure")
+    m.label = lambda mask: ndimage.label(mask, structure=np.ones((3,) * np.ndim(mask), bool))[0]
+    sys.modules["skimage.measure"] = m
+    sys.modules["skimage"].measure = m
+
+
+CONSUMER_CASES = [  # name, feature kind, (h_patch, w_patch), eig grid factor, K, numpy seed, kwargs
+    ("fixed4", "blobs", (14, 14), 1, 6, 11, dict()),
+    ("adaptive", "blobs", (14, 14), 1, 8, 12, dict(adaptive=True)),
+    ("three_no_bg", "blobs", (11, 17), 1, 5, 13, dict(non_adaptive_num_segments=3, infer_bg_index=False)),
+    ("kmeans_baseline", "blobs", (14, 14), 1, 4, 14, dict(kmeans_baseline=True, non_adaptive_num_segments=5)),
+    ("two_eigenvectors", "blobs", (20, 15), 1, 6, 15, dict(num_eigenvectors=2, non_adaptive_num_segments=3)),
+    ("upsampled2x", "blobs", (14, 14), 2, 5, 16, dict()),
+]
+BBOX_CASES = [  # name, kwargs of extract_bboxes
+    ("default", dict()),
+    ("e2_d5", dict(num_erode=2, num_dilate=5)),
+    ("with_bg_e0_d0", dict(num_erode=0, num_dilate=0, skip_bg_index=False)),
+    ("e6_d1", dict(num_erode=6, num_dilate=1)),
+]
+
+
+def _consumer_inputs(name, kind, hw, factor, K, tmp):
+    """Feature + eigen files of one case, as the reference's own stages would have written them."""
+    n = hw[0] * hw[1]
+    feats = synthetic.synthetic_features(kind, n, 384, 500 + len(name), hw)
+    ghw = (hw[0] * factor, hw[1] * factor)
+    efeats = feats if factor == 1 else synthetic.synthetic_features(kind, ghw[0] * ghw[1], 384, 500 + len(name), ghw)
+    lam, vec = spectral_ref.ref_laplacian_eigs(torch.from_numpy(efeats), K)
+    fdir, edir = Path(tmp) / "f", Path(tmp) / "e"
+    fdir.mkdir(exist_ok=True), edir.mkdir(exist_ok=True)
+    torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": f"{name}.jpg", "id": name,
+                "model_name": "dino_vits16", "patch_size": 16, "shape": (1, 3, hw[0] * 16 + 5, hw[1] * 16 + 9)},
+               fdir / f"{name}.pth")
+    torch.save({"eigenvalues": lam.float(), "eigenvectors": vec}, edir / f"{name}.pth")
+    return feats, lam.float().numpy(), vec.numpy()
+
+
+def make_consumer_goldens(ref):
+    """Reference ``extract_multi_region_segmentations`` (extract.py:283-377, seeded through numpy's global state, which
+    is what sklearn's KMeans draws from) and ``extract_bboxes`` (:429-495) on the PNGs it produced."""
+    import json
+    from PIL import Image
+
+    ref.utils.binary_erosion, ref.utils.binary_dilation = _ndimage_morphology()
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        sdir = Path(tmp) / "s"
+        sdir.mkdir()
+        for name, kind, hw, factor, K, seed, kw in CONSUMER_CASES:
+            with tempfile.TemporaryDirectory() as one:
+                _, lam, vec = _consumer_inputs(name, kind, hw, factor, K, one)
+                np.random.seed(seed)
+                ref.extract_multi_region_segmentations(features_dir=str(Path(one) / "f"), eigs_dir=str(Path(one) / "e"),
+                                                       output_dir=str(Path(one) / "o"), **kw)
+                png = np.array(Image.open(Path(one) / "o" / f"{name}.png"))
+            _consumer_inputs(name, kind, hw, factor, K, tmp)       # same files again, all cases side by side
+            Image.fromarray(png).save(sdir / f"{name}.png")
+            out[f"{name}__eigenvalues"], out[f"{name}__eigenvectors"], out[f"{name}__png"] = lam, vec, png
+            print(f"[golden] multi_region {name}: png {png.shape} labels {np.unique(png).tolist()}")
+        for bname, kw in BBOX_CASES:
+            ofile = Path(tmp) / f"bboxes_{bname}.pth"
+            ref.extract_bboxes(features_dir=str(Path(tmp) / "f"), segmentations_dir=str(sdir), output_file=str(ofile), **kw)
+            boxes = torch.load(ofile, weights_only=False)
+            plain = [{k: (v if isinstance(v, str) else [[int(x) for x in b] if isinstance(b, list) else int(b) for b in v])
+                      for k, v in d.items()} for d in boxes]
+            out[f"bboxes__{bname}"] = np.array(json.dumps(plain))
+            print(f"[golden] bboxes {bname}: {[len(d['bboxes']) for d in plain]} boxes per image")
+        # upsampled case again with the factor the segmentation grid needs (P = 8 for a 2x grid)
+        one = [c for c in CONSUMER_CASES if c[0] == "upsampled2x"][0]
+        ofile = Path(tmp) / "bboxes_ds8.pth"
+        with tempfile.TemporaryDirectory() as t2:
+            _consumer_inputs(one[0], one[1], one[2], one[3], one[4], t2)
+            (Path(t2) / "s").mkdir()
+            Image.fromarray(out["upsampled2x__png"]).save(Path(t2) / "s" / "upsampled2x.png")
+            ref.extract_bboxes(features_dir=str(Path(t2) / "f"), segmentations_dir=str(Path(t2) / "s"),
+                               output_file=str(ofile), downsample_factor=8)
+        boxes = torch.load(ofile, weights_only=False)
+        out["bboxes__upsampled2x_ds8"] = np.array(json.dumps(
+            [{k: (v if isinstance(v, str) else [[int(x) for x in b] if isinstance(b, list) else int(b) for b in v])
+              for k, v in d.items()} for d in boxes]))
+    np.savez_compressed(GOLDEN / "consumers.npz",
+                        cases=np.array(json.dumps([[c[0], c[1], list(c[2]), c[3], c[4], c[5], c[6]] for c in CONSUMER_CASES])),
+                        bbox_cases=np.array(json.dumps(BBOX_CASES)), **out)
+
+
+def _jpeg_bytes(img_u8: np.ndarray) -> bytes:
+    import io
+    from PIL import Image
+
+    buf = io.BytesIO()
+    Image.fromarray(img_u8).save(buf, format="JPEG", quality=92)
+    return buf.getvalue()
+
+
+class _cuda_is_cpu:
+    """``.to('cuda')`` -> no-op while the reference's ``extract_bbox_features`` runs on this GPU-less box."""
+
+    def __enter__(self):
+        self.t, self.m = torch.Tensor.to, torch.nn.Module.to
+        t, m = self.t, self.m
+        torch.Tensor.to = lambda s, *a, **k: s if a and a[0] == "cuda" else t(s, *a, **k)
+        torch.nn.Module.to = lambda s, *a, **k: s if a and a[0] == "cuda" else m(s, *a, **k)
+
+    def __exit__(self, *exc):
+        torch.Tensor.to, torch.nn.Module.to = self.t, self.m
+
+
+BBOX_FEATURE_IMAGES = [("crop_a", 112, 160), ("crop_b", 96, 96)]
+BBOX_FEATURE_BOXES = {  # pixel boxes (xmin, ymin, xmax, ymax), multiples of the patch size like extract_bboxes writes
+    "crop_a": [[0, 0, 160, 112], [16, 32, 80, 96], [96, 16, 160, 80], [32, 0, 48, 16]],
+    "crop_b": [[16, 16, 80, 80], [0, 48, 96, 96]],
+}
+
+
+def make_bbox_feature_golden(ref):
+    """Reference ``extract_bbox_features`` (extract.py:498-544): CLS output of the full ViT on every box crop."""
+    sd = synthetic.synthetic_state_dict(FEATURE_MODEL, FEATURE_WEIGHT_SEED, FEATURE_LN_JITTER)
+    torch.hub.load = lambda repo, name, *a, **k: vit_ref.build_ref_vit(name, sd)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = Path(tmp) / "images"
+        root.mkdir()
+        bbox_list = []
+        for i, (name, h, w) in enumerate(BBOX_FEATURE_IMAGES):
+            data = _jpeg_bytes(synthetic.synthetic_image(700 + i, h, w))
+            (root / f"{name}.jpg").write_bytes(data)
+            out[f"{name}__jpeg"] = np.frombuffer(data, np.uint8)
+            bbox_list.append({"id": name, "bboxes_original_resolution": BBOX_FEATURE_BOXES[name],
+                              "bboxes": [[v // 16 for v in b] for b in BBOX_FEATURE_BOXES[name]]})
+        torch.save(bbox_list, Path(tmp) / "bboxes.pth")
+        with _cuda_is_cpu():
+            ref.extract_bbox_features(images_root=str(root), bbox_file=str(Path(tmp) / "bboxes.pth"),
+                                      model_name=FEATURE_MODEL, output_file=str(Path(tmp) / "out.pth"))
+        res = torch.load(Path(tmp) / "out.pth", weights_only=False)
+    for d in res:
+        out[f"{d['id']}__features"] = d["features"].numpy()
+        out[f"{d['id']}__boxes"] = np.array(d["bboxes_original_resolution"])
+        print(f"[golden] bbox_features {d['id']}: {tuple(d['features'].shape)} |f| {d['features'].norm(dim=1).tolist()}")
+    np.savez_compressed(GOLDEN / "bbox_features.npz", model=FEATURE_MODEL, weight_seed=FEATURE_WEIGHT_SEED,
+                        ln_jitter=FEATURE_LN_JITTER, names=np.array([n for n, _, _ in BBOX_FEATURE_IMAGES]), **out)
+
+
+COLOR_CASES = [  # name, (h_patch, w_patch), K, kwargs of _extract_eig
+    ("knn_lambda10", (14, 14), 5, dict(image_color_lambda=10.0)),
+    ("knn_lambda1_lapnorm_false", (12, 16), 4, dict(image_color_lambda=1.0, lapnorm=False)),
+    ("knn_lambda10_upsample8", (9, 11), 4, dict(image_color_lambda=10.0, image_downsample_factor=8)),
+]
+
+
+def make_color_goldens(ref):
+    """Reference ``_extract_eig`` with a KNN colour affinity (extract.py:197-222, extract_utils.py:150-189).  pymatting
+    is absent: ``pymatting.util.kdtree.knn(data, query, k)`` -> (distances, indices) is provided by an exhaustive exact
+    search over the same float32 points (fp64 distances).  On 8-bit colours EXACT ties at the k-th neighbour are common
+    and a kd-tree breaks them by traversal order; the stand-in breaks them toward the lower index, the rule the product
+    documents (scipy's cKDTree agrees everywhere else: tests/test_consumers.py)."""
+
+    def knn(data, query, k):
+        d, q = np.asarray(data, np.float64), np.asarray(query, np.float64)
+        d2 = ((q[:, None, :] - d[None, :, :]) ** 2).sum(-1)
+        idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
+        return np.sqrt(np.take_along_axis(d2, idx, 1)), idx
+
+    kd = types.ModuleType("pymatting.util.kdtree")
+    kd.knn = knn
+    sys.modules["pymatting.util.kdtree"] = kd
+    sys.modules["pymatting.util"].kdtree = kd
+    for name, hw, K, kw in COLOR_CASES:
+        n = hw[0] * hw[1]
+        feats = synthetic.synthetic_features("blobs", n, 384, 900 + len(name), hw)
+        H, W = hw[0] * 16 + 7, hw[1] * 16 + 3
+        jpeg = _jpeg_bytes(synthetic.synthetic_image(800 + len(name), H, W))
+        with tempfile.TemporaryDirectory() as tmp:
+            fdir, odir, root = Path(tmp) / "f", Path(tmp) / "o", Path(tmp) / "i"
+            fdir.mkdir(), odir.mkdir(), root.mkdir()
+            (root / f"{name}.jpg").write_bytes(jpeg)
+            torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": f"{name}.jpg", "id": name,
+                        "model_name": "dino_vits16", "patch_size": 16, "shape": (1, 3, H, W)}, fdir / f"{name}.pth")
+            ref._extract_eig((0, str(fdir / f"{name}.pth")), K=K, images_root=str(root), output_dir=str(odir),
+                             which_matrix="laplacian", **kw)
+            res = torch.load(odir / f"{name}.pth", map_location="cpu", weights_only=False)
+        ev, vec = np.asarray(res["eigenvalues"]), res["eigenvectors"].numpy()
+        np.savez_compressed(GOLDEN / f"color_{name}.npz", hw=np.array(hw), K=K, kwargs=np.array(repr(kw)),
+                            feature_seed=900 + len(name), shape=np.array((1, 3, H, W)),
+                            jpeg=np.frombuffer(jpeg, np.uint8), eigenvalues=ev, eigenvectors=vec)
+        print(f"[golden] color_{name}: ev={ev} vec{vec.shape}")
+
+
+def make_localization_golden(ref):
+    """Reference ``get_bbox_from_patch_mask`` / ``get_largest_cc_box`` (object-localization/object_discovery.py:85-126,
+    280-287) and ``bbox_iou`` (datasets.py:269-294) on seeded masks.  The module's unrelated imports (torchvision,
+    skimage.io, traitlets) are inert stubs; ``skimage.measure.label`` is the scipy.ndimage stand-in."""
+    import json
+
+    _install_skimage_label()
+    for name in ("skimage.io", "traitlets", "traitlets.traitlets"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["traitlets.traitlets"].default = None
+    sys.modules["skimage"].io = sys.modules["skimage.io"]
+    sys.path.insert(0, str(REFERENCE / "object-localization"))
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "datasets" or k.startswith("datasets.")}
+    try:
+        spec = importlib.util.spec_from_file_location("ref_object_discovery",
+                                                      REFERENCE / "object-localization" / "object_discovery.py")
+        od = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(od)
+        ref_iou = sys.modules["datasets"].bbox_iou
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(77)
+    cases = []
+    # (C, H, W) padded image sizes x mask grids: patch 8, patch 16, 16 upsampled 2x, ambiguous sizes, inverted / empty
+    specs = [((3, 224, 224), 16, 1), ((3, 224, 224), 8, 1), ((3, 224, 224), 16, 2), ((3, 160, 240), 16, 1),
+             ((3, 176, 96), 8, 1), ((3, 480, 480), 16, 1), ((3, 64, 64), 32, 4), ((3, 333, 500), 16, 1),
+             ((3, 333, 500), 8, 1), ((3, 500, 375), 16, 2)]
+    for size, p, up in specs:
+        hl, wl = up * (size[1] // p), up * (size[2] // p)
+        for kind in ("blob", "two_blobs", "majority", "empty", "noise", "full"):
+            yy, xx = np.mgrid[0:hl, 0:wl]
+            if kind == "blob":
+                m = ((yy - hl * 0.4) ** 2 + (xx - wl * 0.6) ** 2) < (min(hl, wl) * 0.3) ** 2
+            elif kind == "two_blobs":
+                m = (((yy - 1) ** 2 + (xx - 1) ** 2) < 6) | (((yy - hl + 3) ** 2 + (xx - wl + 4) ** 2) < 14)
+            elif kind == "majority":
+                m = ~(((yy - hl * 0.5) ** 2 + (xx - wl * 0.3) ** 2) < (min(hl, wl) * 0.25) ** 2)
+            elif kind == "empty":
+                m = np.zeros((hl, wl), bool)
+            elif kind == "full":
+                m = np.ones((hl, wl), bool)
+            else:
+                m = rng.random((hl, wl)) < 0.35
+            try:
+                pred = od.get_bbox_from_patch_mask(torch.from_numpy(m.reshape(-1)), size).tolist()
+            except ValueError as e:  # a 'full' mask: nothing left after no inversion? keep what the reference does
+                pred = f"ValueError"
+            cases.append({"size": list(size), "mask_hw": [hl, wl], "kind": kind,
+                          "mask": np.packbits(m.reshape(-1)).tolist(), "pred": pred})
+    boxes = rng.integers(0, 200, size=(12, 2))
+    boxes = np.concatenate([boxes, boxes + rng.integers(1, 150, size=(12, 2))], axis=1).astype(np.float64)
+    ious = [ref_iou(torch.from_numpy(boxes[i]), torch.from_numpy(boxes)).tolist() for i in range(4)]
+    sys.modules.pop("datasets", None)
+    sys.modules.update(saved)
+    np.savez_compressed(GOLDEN / "localization.npz", cases=np.array(json.dumps(cases)), iou_boxes=boxes,
+                        ious=np.array(ious))
+    print(f"[golden] localization: {len(cases)} masks; preds e.g. {[c['pred'] for c in cases[:6]]}")
+
+
 def main():
     assert REFERENCE.is_dir(), "make_golden.py runs only where /root/reference is mounted"
     GOLDEN.mkdir(parents=True, exist_ok=True)
@@ -423,7 +683,9 @@ def main():
     ref = _import_reference()
     only = set(sys.argv[1:])  # e.g. `python oracle/make_golden.py eigs modes`; nothing = everything
     steps = {"probe": make_index_probe, "features": make_feature_goldens, "eigs": make_eig_goldens,
-             "single_region": make_single_region_golden, "modes": make_mode_goldens}
+             "single_region": make_single_region_golden, "modes": make_mode_goldens,
+             "consumers": make_consumer_goldens, "bbox_features": make_bbox_feature_golden, "color": make_color_goldens,
+             "localization": make_localization_golden}
     assert only <= set(steps), f"unknown step(s) {only - set(steps)}; known: {sorted(steps)}"
     for name, fn in steps.items():
         if not only or name in only:

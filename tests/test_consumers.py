@@ -1,0 +1,339 @@
+"""the consumers / options either side of the hot path, each pinned to outputs of the REFERENCE ITSELF
+(oracle/make_golden.py `consumers`, `localization`, `bbox_features`, `color` -> tests/golden/*.npz).
+
+CPU tests: multi-region segmentation, boxes, eigensegment -> box (host-side bookkeeping, bit-exact).
+GPU tests (`-m gpu`): colour-affinity fusion through the Lanczos kernel, box-crop CLS features through the ViT kernels,
+the inline localization eigenvectors."""
+import inspect
+import io
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import dss_amd  # noqa: F401
+from dss_amd import extract, extract_utils, object_discovery, synthetic
+
+REPO = Path(__file__).resolve().parents[1]
+GOLDEN = REPO / "tests" / "golden"
+
+
+def _write_case(tmp: Path, g, name, kind, hw, factor, K):
+    """The feature + eigen files oracle/make_golden._consumer_inputs wrote for this case (eigenpairs from the golden)."""
+    n = hw[0] * hw[1]
+    feats = synthetic.synthetic_features(kind, n, 384, 500 + len(name), tuple(hw))
+    (tmp / "f").mkdir(exist_ok=True), (tmp / "e").mkdir(exist_ok=True)
+    torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": f"{name}.jpg", "id": name,
+                "model_name": "dino_vits16", "patch_size": 16, "shape": (1, 3, hw[0] * 16 + 5, hw[1] * 16 + 9)},
+               tmp / "f" / f"{name}.pth")
+    torch.save({"eigenvalues": torch.from_numpy(g[f"{name}__eigenvalues"]),
+                "eigenvectors": torch.from_numpy(g[f"{name}__eigenvectors"])}, tmp / "e" / f"{name}.pth")
+
+
+def _cases(g):
+    return json.loads(str(g["cases"]))
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_multi_region_segmentation_matches_reference(tmp_path, case):
+    """extract/extract.py:283-377: same PNG, bit for bit, as the reference run with the same numpy seed (KMeans draws
+    its k-means++ seeds from numpy's global state in both)."""
+    from PIL import Image
+
+    g = np.load(GOLDEN / "consumers.npz")
+    name, kind, hw, factor, K, seed, kw = _cases(g)[case]
+    _write_case(tmp_path, g, name, kind, hw, factor, K)
+    np.random.seed(seed)
+    extract.extract_multi_region_segmentations(features_dir=str(tmp_path / "f"), eigs_dir=str(tmp_path / "e"),
+                                               output_dir=str(tmp_path / "o"), **kw)
+    png = np.array(Image.open(tmp_path / "o" / f"{name}.png"))
+    want = g[f"{name}__png"]
+    assert png.dtype == want.dtype == np.uint8 and png.shape == want.shape
+    assert np.array_equal(png, want), f"{name}: {(png != want).sum()} of {png.size} labels differ"
+    if kw.get("infer_bg_index", True):   # the segment owning most of the border is 0
+        idx, frac = extract_utils.get_border_fraction(png)
+        assert idx[np.argmax(frac)] == 0
+    # skip-if-exists, like every command of the reference
+    before = (tmp_path / "o" / f"{name}.png").stat().st_mtime_ns
+    extract._extract_multi_region_segmentations(
+        (0, (str(tmp_path / "f" / f"{name}.pth"), str(tmp_path / "e" / f"{name}.pth"))), adaptive=False,
+        non_adaptive_num_segments=2, infer_bg_index=True, kmeans_baseline=False, output_dir=str(tmp_path / "o"),
+        num_eigenvectors=10)
+    assert (tmp_path / "o" / f"{name}.png").stat().st_mtime_ns == before
+
+
+def test_multi_region_rejects_a_grid_that_is_neither_1x_nor_2x(tmp_path):
+    g = np.load(GOLDEN / "consumers.npz")
+    name, kind, hw, factor, K, seed, kw = _cases(g)[0]
+    _write_case(tmp_path, g, name, kind, hw, factor, K)
+    d = torch.load(tmp_path / "e" / f"{name}.pth")
+    d["eigenvectors"] = d["eigenvectors"][:, :100]
+    torch.save(d, tmp_path / "e" / f"{name}.pth")
+    with pytest.raises(ValueError):
+        extract.extract_multi_region_segmentations(str(tmp_path / "f"), str(tmp_path / "e"), str(tmp_path / "o"))
+
+
+def _bbox_dirs(tmp_path, g, only=None):
+    from PIL import Image
+
+    (tmp_path / "s").mkdir()
+    for name, kind, hw, factor, K, seed, kw in _cases(g):
+        if only is None or name == only:
+            _write_case(tmp_path, g, name, kind, hw, factor, K)
+            Image.fromarray(g[f"{name}__png"]).save(tmp_path / "s" / f"{name}.png")
+
+
+@pytest.mark.parametrize("bcase", range(4))
+def test_extract_bboxes_matches_reference(tmp_path, bcase):
+    """extract/extract.py:429-495 on the reference's own segmentation PNGs: same list of dicts in one .pth file."""
+    g = np.load(GOLDEN / "consumers.npz")
+    bname, kw = json.loads(str(g["bbox_cases"]))[bcase]
+    _bbox_dirs(tmp_path, g)
+    out = tmp_path / "boxes" / "b.pth"
+    extract.extract_bboxes(features_dir=str(tmp_path / "f"), segmentations_dir=str(tmp_path / "s"),
+                           output_file=str(out), **kw)
+    got = torch.load(out, weights_only=False)
+    want = json.loads(str(g[f"bboxes__{bname}"]))
+    assert len(got) == len(want) == 6
+    for a, b in zip(got, want):
+        assert set(a) == {"bboxes", "bboxes_original_resolution", "segment_indices", "id", "format"}
+        assert a["id"] == b["id"] and a["format"] == b["format"] == "(xmin, ymin, xmax, ymax)"
+        assert a["segment_indices"] == b["segment_indices"]
+        assert a["bboxes"] == b["bboxes"], (a["id"], a["bboxes"], b["bboxes"])
+        assert a["bboxes_original_resolution"] == b["bboxes_original_resolution"]
+
+
+def test_extract_bboxes_downsample_factor(tmp_path):
+    g = np.load(GOLDEN / "consumers.npz")
+    _bbox_dirs(tmp_path, g, only="upsampled2x")
+    extract.extract_bboxes(str(tmp_path / "f"), str(tmp_path / "s"), str(tmp_path / "b.pth"), downsample_factor=8)
+    got = torch.load(tmp_path / "b.pth", weights_only=False)
+    want = json.loads(str(g["bboxes__upsampled2x_ds8"]))
+    assert [d["bboxes_original_resolution"] for d in got] == [d["bboxes_original_resolution"] for d in want]
+    assert all(v % 8 == 0 for d in got for b in d["bboxes_original_resolution"] for v in b)
+
+
+def test_morphology_and_components_follow_skimage_conventions():
+    m = np.zeros((7, 9), bool)
+    m[0:3, 0:3] = True            # touches the border: skimage's erosion treats outside as set -> corner survives
+    m[4, 5] = True
+    er = extract_utils.erode_or_dilate_mask(m, 1, erode=True)
+    assert er[0, 0] and er[1, 1] and not er[2, 2] and not er[4, 5] and er.sum() == 4
+    assert extract_utils.erode_or_dilate_mask(m, 50, erode=True).sum() > 0      # never erodes everything away
+    di = extract_utils.erode_or_dilate_mask(m, 1, erode=False)
+    assert di[3, 5] and di[4, 4] and not di[3, 4]                               # cross footprint, not a square
+    # 8-connectivity: diagonal neighbours are one component
+    c = np.zeros((5, 5), bool)
+    c[0, 0] = c[1, 1] = c[2, 2] = True
+    c[4, 0] = c[4, 1] = True
+    assert extract_utils.get_largest_cc(c).sum() == 3
+    with pytest.raises(ValueError):
+        extract_utils.get_largest_cc(np.zeros((3, 3), bool))
+    seg = np.array([[1, 1, 2], [0, 5, 2], [0, 0, 2]])
+    idx, frac = extract_utils.get_border_fraction(seg)
+    assert idx.tolist() == [0, 1, 2, 5] and np.allclose(frac * 12, [4, 3, 5, 0])   # corners count twice
+
+
+def test_bbox_from_patch_mask_matches_reference():
+    """object-localization/object_discovery.py:85-126 on 60 seeded masks (patch 8 / 16 / upsampled grids, inverted,
+    empty and full masks, sizes where two grids are possible)."""
+    g = np.load(GOLDEN / "localization.npz")
+    for c in json.loads(str(g["cases"])):
+        hl, wl = c["mask_hw"]
+        m = np.unpackbits(np.array(c["mask"], np.uint8))[:hl * wl].astype(bool)
+        pred = object_discovery.get_bbox_from_patch_mask(torch.from_numpy(m), tuple(c["size"]))
+        assert pred.tolist() == c["pred"], (c["size"], c["kind"], pred, c["pred"])
+    with pytest.raises(ValueError):
+        object_discovery.get_bbox_from_patch_mask(torch.zeros(13, dtype=torch.bool), (3, 224, 224))
+    boxes = torch.from_numpy(g["iou_boxes"])
+    for i in range(4):
+        assert torch.allclose(object_discovery.bbox_iou(boxes[i], boxes), torch.from_numpy(g["ious"][i]), rtol=0, atol=1e-12)
+
+
+def test_consumer_commands_keep_the_reference_signatures():
+    sig = inspect.signature(extract.extract_multi_region_segmentations).parameters
+    assert list(sig) == ["features_dir", "eigs_dir", "output_dir", "adaptive", "non_adaptive_num_segments",
+                         "infer_bg_index", "kmeans_baseline", "num_eigenvectors", "multiprocessing"]
+    assert (sig["adaptive"].default, sig["non_adaptive_num_segments"].default, sig["infer_bg_index"].default,
+            sig["kmeans_baseline"].default, sig["num_eigenvectors"].default) == (False, 4, True, False, 1_000_000)
+    sig = inspect.signature(extract.extract_bboxes).parameters
+    assert list(sig) == ["features_dir", "segmentations_dir", "output_file", "num_erode", "num_dilate", "skip_bg_index",
+                         "downsample_factor"]
+    assert (sig["num_erode"].default, sig["num_dilate"].default, sig["skip_bg_index"].default) == (2, 3, True)
+    assert list(inspect.signature(extract.extract_bbox_features).parameters)[:4] == \
+        ["images_root", "bbox_file", "model_name", "output_file"]
+    for cmd in ("extract_multi_region_segmentations", "extract_bboxes", "extract_bbox_features"):
+        assert cmd in extract.COMMANDS
+    fn, kw = extract.parse_cli(["extract_bboxes", "--features_dir", "f", "--segmentations_dir", "s", "--num_erode", "2",
+                                "--num_dilate", "5", "--output_file", "o.pth"])
+    assert fn is extract.extract_bboxes and kw["num_dilate"] == 5
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _np_knn_affinity(image, n_neighbors=(20, 10), distance_weights=(2.0, 0.1)):
+    """extract_utils.py:150-189 restated on the host with an exact kd-tree (test-side check of the GPU builder)."""
+    import scipy.sparse
+    from scipy.spatial import cKDTree
+
+    h, w = image.shape[:2]
+    r, g, b = image.reshape(-1, 3).T
+    n = w * h
+    x = np.tile(np.linspace(0, 1, w), h)
+    y = np.repeat(np.linspace(0, 1, h), w)
+    i, j = [], []
+    for k, dw in zip(n_neighbors, distance_weights):
+        f = np.stack([r, g, b, dw * x, dw * y], axis=1, out=np.zeros((n, 5), dtype=np.float32))
+        _, nb = cKDTree(f).query(f, k=k)
+        i.append(np.repeat(np.arange(n), k))
+        j.append(nb.flatten())
+    ij, ji = np.concatenate(i + j), np.concatenate(j + i)
+    return np.asarray(scipy.sparse.csr_matrix((np.ones(2 * sum(n_neighbors) * n), (ij, ji)), (n, n)).todense())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(14, 14), (18, 22), (30, 30)])
+def test_knn_affinity_on_gpu_matches_kdtree(hw):
+    img = synthetic.synthetic_image(31, hw[0], hw[1]).astype(np.float64) / 255.0
+    got = extract_utils.knn_affinity(torch.from_numpy(img).cuda()).cpu().numpy()
+    want = _np_knn_affinity(img)
+    assert got.shape == want.shape and np.array_equal(got, got.T)
+    # identical to the kd-tree's graph except in rows where the k-th and (k+1)-th neighbour are at EXACTLY the same
+    # distance (8-bit colours on a regular grid): there the kd-tree's traversal order decides, here the lower index
+    tied = np.zeros(got.shape[0], bool)
+    h, w = hw
+    x, y = np.tile(np.linspace(0, 1, w), h), np.repeat(np.linspace(0, 1, h), w)
+    for k, dw in ((20, 2.0), (10, 0.1)):
+        f = np.concatenate([img.reshape(-1, 3), (dw * x)[:, None], (dw * y)[:, None]], 1).astype(np.float32).astype(np.float64)
+        d2 = np.sort(((f[:, None] - f[None]) ** 2).sum(-1), axis=1)
+        tied |= d2[:, k - 1] == d2[:, k]
+    bad = np.argwhere(got != want)
+    assert all(tied[i] or tied[j] for i, j in bad), f"{len(bad)} entries differ outside tied rows"
+    assert len(bad) <= 4 * tied.sum()
+    assert np.all(np.diag(got) == 4) and got.sum() == 2 * 30 * hw[0] * hw[1]
+    with pytest.raises(ValueError):
+        extract_utils.knn_affinity(torch.zeros(3, 3, 3).cuda())      # 9 pixels, 20 neighbours asked
+
+
+@pytest.mark.gpu
+def test_rw_affinity_on_gpu_matches_pixel_loop():
+    """Scalar restatement of the documented random-walk weights (window r = 1, clamped coordinates, duplicates add)."""
+    img = synthetic.synthetic_image(32, 9, 7).astype(np.float64) / 255.0
+    h, w = img.shape[:2]
+    want = np.zeros((h * w, h * w))
+    for y in range(h):
+        for x in range(w):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    y2, x2 = max(0, min(h - 1, y + dy)), max(0, min(w - 1, x + dx))
+                    want[x + y * w, x2 + y2 * w] += np.exp(-np.sum((img[y, x] - img[y2, x2]) ** 2) / 0.033 ** 2)
+    got = extract_utils.rw_affinity(torch.from_numpy(img).cuda()).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-9) and np.allclose(got, got.T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["knn_lambda10", "knn_lambda1_lapnorm_false", "knn_lambda10_upsample8"])
+def test_color_affinity_eigs_match_reference(tmp_path, name):
+    """extract/extract.py:197-240 with image_color_lambda > 0, through the CLI-level function: W_feat / max + lambda *
+    W_knn built on the GPU, packed, solved by the same Lanczos kernel; compared with the reference's own output."""
+    import ast
+    from tests.util import check_eigs
+
+    g = np.load(GOLDEN / f"color_{name}.npz")
+    hw, K, kw = tuple(g["hw"]), int(g["K"]), ast.literal_eval(str(g["kwargs"]))
+    feats = synthetic.synthetic_features("blobs", hw[0] * hw[1], 384, int(g["feature_seed"]), hw)
+    (tmp_path / "f").mkdir(), (tmp_path / "i").mkdir(), (tmp_path / "o").mkdir()
+    (tmp_path / "i" / f"{name}.jpg").write_bytes(g["jpeg"].tobytes())
+    torch.save({"k": torch.from_numpy(feats)[None], "indices": torch.tensor(0), "file": f"{name}.jpg", "id": name,
+                "model_name": "dino_vits16", "patch_size": 16, "shape": tuple(int(v) for v in g["shape"])},
+               tmp_path / "f" / f"{name}.pth")
+    extract.extract_eigs(images_root=str(tmp_path / "i"), features_dir=str(tmp_path / "f"),
+                         output_dir=str(tmp_path / "o"), which_matrix="laplacian", K=K, **kw)
+    out = torch.load(tmp_path / "o" / f"{name}.pth", weights_only=False)
+    vec, lam = out["eigenvectors"].numpy(), np.asarray(out["eigenvalues"])
+    assert vec.shape == g["eigenvectors"].shape and out["eigenvectors"].dtype == torch.float32
+    scale = max(1.0, float(np.abs(g["eigenvalues"]).max()))
+    check_eigs(vec, lam / scale, g["eigenvectors"], g["eigenvalues"] / scale, what=name, lam_tol=2e-5)
+    ratio = np.linalg.norm(vec, axis=1) / np.linalg.norm(g["eigenvectors"], axis=1)
+    assert np.allclose(ratio, 1.0, atol=1e-3), ratio      # ARPACK's normalisation (v^T D v = 1 / unit vectors) kept
+
+
+@pytest.mark.gpu
+def test_bbox_features_match_reference(tmp_path):
+    """extract/extract.py:498-544: CLS output (12 blocks + final LayerNorm) of every box crop.  The reference ran in
+    fp32; the kernels use f16 operands with fp32 accumulation: compared by cosine and by relative L2."""
+    g = np.load(GOLDEN / "bbox_features.npz")
+    (tmp_path / "i").mkdir()
+    bbox_list = []
+    for name in g["names"]:
+        (tmp_path / "i" / f"{name}.jpg").write_bytes(g[f"{name}__jpeg"].tobytes())
+        boxes = g[f"{name}__boxes"].tolist()
+        bbox_list.append({"id": str(name), "bboxes_original_resolution": boxes, "bboxes": [[v // 16 for v in b] for b in boxes]})
+    torch.save(bbox_list, tmp_path / "b.pth")
+    sd = synthetic.synthetic_state_dict(str(g["model"]), int(g["weight_seed"]), float(g["ln_jitter"]))
+    torch.save(sd, tmp_path / "w.pth")
+    extract.extract_bbox_features(images_root=str(tmp_path / "i"), bbox_file=str(tmp_path / "b.pth"),
+                                  model_name=str(g["model"]), output_file=str(tmp_path / "o.pth"),
+                                  weights=str(tmp_path / "w.pth"))
+    out = torch.load(tmp_path / "o.pth", weights_only=False)
+    assert [d["id"] for d in out] == [str(n) for n in g["names"]]
+    for d in out:
+        got, want = d["features"].double().numpy(), g[f"{d['id']}__features"].astype(np.float64)
+        assert d["features"].dtype == torch.float32 and got.shape == want.shape
+        rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+        assert rel.max() < 5e-3, rel
+        # the crops must be told apart: differences between boxes are reproduced, not just the common mean
+        dw, dg = want - want.mean(0), got - got.mean(0)
+        cos = (dw * dg).sum(1) / (np.linalg.norm(dw, axis=1) * np.linalg.norm(dg, axis=1))
+        assert cos.min() > 0.99, cos
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["laplacian", "affinity"])
+def test_inline_localization_eigenvectors(which):
+    """object-localization/object_discovery.py:16-41 (features NOT normalised there) through the GPU solver, against
+    the same lines restated with scipy."""
+    from scipy.sparse.linalg import eigsh
+    from oracle.spectral_ref import cos_err
+
+    feats = synthetic.synthetic_features("blobs", 196, 384, 21, (14, 14)) * np.linspace(0.5, 2.0, 196, dtype=np.float32)[:, None]
+    vec = object_discovery.get_eigenvectors_from_features(torch.from_numpy(feats).cuda()[None], which, K=3).cpu().numpy()
+    a = (feats @ feats.T).astype(np.float32)
+    if which == "affinity":
+        _, v = eigsh(a, which="LM", k=3)
+        want = v[:, ::-1].T
+    else:
+        w = a * (a > 0)
+        w = w / w.max()
+        d = w @ np.ones(w.shape[0])
+        d[d < 1e-12] = 1.0
+        _, v = eigsh(np.diag(d) - w, k=3, sigma=0, which="LM", M=np.diag(d))
+        want = v.T
+    assert vec.shape == (3, 196)
+    assert cos_err(vec, want).max() < 1e-4, cos_err(vec, want)
+    mask = torch.from_numpy(vec[1 if which == "laplacian" else 0] > 0)
+    box = object_discovery.get_bbox_from_patch_mask(mask, (3, 224, 224))
+    assert box.shape == (4,) and box[2] > box[0] and box[3] > box[1] and box[2] <= 224
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 196, 713])
+def test_dense_affinity_packing_round_trip_and_solver_agreement(n):
+    """affinity_from_dense is the inverse of affinity_to_dense, and the dense-W entry point of the solver gives what the
+    feature entry point gives for the same matrix."""
+    from dss_amd import hip, spectral
+    from oracle.spectral_ref import cos_err
+
+    feats = torch.from_numpy(synthetic.synthetic_features("blobs", n, 384, 5, {64: (8, 8), 196: (14, 14), 713: (23, 31)}[n])).cuda()[None]
+    wp = hip.affinity_split(feats, True, True)
+    dense = hip.affinity_to_dense(wp, n)
+    assert torch.equal(hip.affinity_from_dense(dense[:, :n, :n].contiguous()), wp)
+    w = spectral.feature_affinity_dense(feats)
+    assert w.shape == (1, n, n) and float(w.max()) == 1.0
+    for problem in ("laplacian", "laplacian_unnormalized"):
+        ev1, vec1, info1 = spectral.eigs_from_dense_affinity(w, 4, problem)
+        ev2, vec2, info2 = spectral.laplacian_eigs_from_features(feats, 4, problem=problem, w_dtype="f32")
+        assert int(info1[0]) > 0 and int(info2[0]) > 0
+        assert torch.allclose(ev1, ev2, atol=2e-5 * max(1.0, float(ev2.abs().max())))
+        assert cos_err(vec1[0].cpu().numpy(), vec2[0].cpu().numpy()).max() < 1e-5

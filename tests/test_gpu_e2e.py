@@ -211,7 +211,9 @@ def test_cli_two_stage_roundtrip_and_resume(tmp_path, capsys):
     extract._extract_eig((0, str(tmp_path / "feat" / "b_000.pth")), K=3, images_root="", output_dir=str(tmp_path / "eigs2"),
                          image_color_lambda=0.0)
     assert torch.load(tmp_path / "eigs2" / "b_000.pth", weights_only=True)["eigenvectors"].shape == (3, 48)
-    with pytest.raises(NotImplementedError):
+    # its own default image_color_lambda = 10 (reference extract.py:132) asks for the colour affinity, hence for
+    # <images_root>/<id>.jpg - the synthetic images here are PNGs, as in the reference the open() fails
+    with pytest.raises(FileNotFoundError):
         extract._extract_eig((0, str(tmp_path / "feat" / "a_000.pth")), K=3, images_root="", output_dir=str(tmp_path / "eigs2"))
 
 

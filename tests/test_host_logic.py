@@ -64,8 +64,14 @@ def test_cli_parsing_matches_fire_conventions():
 def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         extract._check_eig_options("affinity_torch", True, 0.0, None, 16)
-    with pytest.raises(NotImplementedError):
-        extract._check_eig_options("laplacian", True, 10.0, None, 16)
+    assert extract._check_eig_options("laplacian", True, 10.0, None, 16) == "laplacian"   # colour fusion is built
+    assert extract._color_spec("laplacian", "knn", 10.0, "root") == (10.0, "knn", "root")
+    assert extract._color_spec("laplacian", "knn", 0.0, "root") is None
+    assert extract._color_spec("affinity", "knn", 10.0, "root") is None      # the affinity branches ignore colour
+    with pytest.raises(ValueError):
+        extract._color_spec("laplacian", "bogus", 1.0, "root")
+    assert extract._lr_grid({"patch_size": 16, "shape": (1, 3, 375, 500)}, 8) == (46, 62)
+    assert extract._lr_grid({"patch_size": 16, "shape": (1, 3, 375, 500)}, None) == (23, 31)
     assert extract._check_eig_options("laplacian", True, 0.0, 8, 16) == "laplacian"   # upsampling is built
     dd = {"patch_size": 16, "shape": (1, 3, 375, 500)}
     assert extract._upsample_spec(dd, "laplacian", 8) == ((23, 31), (46, 62))
