@@ -57,44 +57,6 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def pack_results(ids: torch.Tensor, eigenvalues: torch.Tensor, eigenvectors: torch.Tensor) -> torch.Tensor:
-    """``ids [n]``, ``eigenvalues [n, K]``, ``eigenvectors [n, K, N]`` -> f32 ``[n, K*N + K + 1]``."""
-    n = ids.shape[0]
-    return torch.cat((eigenvectors.reshape(n, -1).float(), eigenvalues.float(),
-                      ids.to(eigenvalues.device).float().view(n, 1)), dim=1).contiguous()
-
-
-def unpack_results(buf: torch.Tensor, K: int, N: int):
-    n = buf.shape[0]
-    vec = buf[:, :K * N].reshape(n, K, N)
-    val = buf[:, K * N:K * N + K]
-    ids = buf[:, -1].round().long()
-    return ids, val, vec
-
-
-def gather_to_root(packed: torch.Tensor, n_total: int):
-    """Gather every rank's packed rows on rank 0 and return them ordered by item id (rank 0) or ``None``.
-    Shards differ by at most one row; they are padded to the common maximum so one ``gather`` suffices."""
-    rank, world = rank_world()
-    if world == 1 or not dist.is_initialized():
-        order = torch.argsort(packed[:, -1])
-        return packed[order]
-    width = packed.shape[1]
-    n_max = (n_total + world - 1) // world
-    dev = packed.device
-    if dist.get_backend() == "gloo":
-        dev = torch.device("cpu")  # gloo gathers host tensors (CPU tests, single-GPU debugging)
-    padded = torch.full((n_max, width), -1.0, dtype=torch.float32, device=dev)
-    padded[: packed.shape[0]] = packed.to(dev)
-    out = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-    dist.gather(padded, out, dst=0)
-    if rank != 0:
-        return None
-    allrows = torch.cat(out)
-    allrows = allrows[allrows[:, -1] >= 0]
-    return allrows[torch.argsort(allrows[:, -1])]
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # Variable-size records (BASELINE config 5: mixed image sizes -> a different N per result): sizes first, then one
 # flat payload per rank.

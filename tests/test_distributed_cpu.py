@@ -1,5 +1,5 @@
-"""CPU, world_size 2 over gloo: the N>1 path - round-robin shards (uneven), the fixed-size gather and the
-sizes-first / flat-payload gather for results of DIFFERENT N (BASELINE config 5), item ids as int64."""
+"""CPU, world_size 2 over gloo: the N>1 path - round-robin shards (uneven) and the sizes-first / flat-payload gather,
+for results of ONE N (BASELINE config 4) and of DIFFERENT N (config 5), item ids as int64."""
 import os
 import socket
 
@@ -29,17 +29,17 @@ def _worker(rank, world, port, q):
     assert distributed.rank_world() == (rank, world)
     mine = distributed.shard_indices(TOTAL, rank, world)
     assert len(mine) == (5 if rank == 0 else 4)
-    # ---- fixed N: the packed-row gather ------------------------------------------------------------------
+    # ---- one N (config 4): the gathered payload is a plain row permutation ----------------------------------
     vals = torch.stack([_fake_result(i)[0] for i in mine])
     vecs = torch.stack([_fake_result(i)[1] for i in mine])
-    out = distributed.gather_to_root(distributed.pack_results(torch.tensor(mine), vals, vecs), TOTAL)
+    out = distributed.gather_records_to_root(*distributed.pack_records(torch.tensor(mine), vals, vecs))
     ok = True
     if rank == 0:
-        ids, v, e = distributed.unpack_results(out, K, N)
-        ok = ids.tolist() == list(range(TOTAL))
-        for i in range(TOTAL):
+        recs = distributed.unpack_records(*out)
+        ok = [r[0] for r in recs] == list(range(TOTAL))
+        for i, (_, v, e) in enumerate(recs):
             rv, re = _fake_result(i)
-            ok = ok and torch.equal(v[i], rv) and torch.equal(e[i], re)
+            ok = ok and torch.equal(v, rv) and torch.equal(e, re)
     else:
         assert out is None
     # ---- mixed N: sizes first, then one flat payload per rank --------------------------------------------

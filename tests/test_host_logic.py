@@ -126,13 +126,15 @@ def test_pack_unpack_and_shard():
     K, N, n = 3, 7, 5
     ids = torch.tensor([9, 2, 4, 0, 7])
     val, vec = torch.randn(n, K), torch.randn(n, K, N)
-    i2, v2, e2 = distributed.unpack_results(distributed.pack_results(ids, val, vec), K, N)
-    assert torch.equal(i2, ids) and torch.equal(v2, val) and torch.equal(e2, vec)
+    recs = distributed.unpack_records(*distributed.pack_records(ids, val, vec))
+    assert [r[0] for r in recs] == ids.tolist()
+    assert all(torch.equal(r[1], val[i]) and torch.equal(r[2], vec[i]) for i, r in enumerate(recs))
     assert distributed.shard_indices(10, 1, 4) == [1, 5, 9]
     allidx = sorted(sum((distributed.shard_indices(10, r, 4) for r in range(4)), []))
     assert allidx == list(range(10))
-    out = distributed.gather_to_root(distributed.pack_results(ids, val, vec), n)
-    assert out[:, -1].tolist() == [0.0, 2.0, 4.0, 7.0, 9.0]
+    meta, payload = distributed.gather_records_to_root(*distributed.pack_records(ids, val, vec))   # world 1: sorts
+    assert meta[:, 0].tolist() == [0, 2, 4, 7, 9] and meta.dtype == torch.int64
+    assert torch.equal(distributed.unpack_records(meta, payload)[0][2], vec[3])
 
 
 def test_synthetic_inputs_are_portable():
