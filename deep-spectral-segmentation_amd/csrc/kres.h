@@ -1,4 +1,4 @@
-// kres.h - pieces shared by the K-resident kernels (linear384.hip, mlp384.hip): LDS-DMA helper types and the
+// kres.h - pieces of the K-resident Linear kernel (linear384.hip): LDS-DMA helper types and the
 // exact-erf GELU on packed fp32.
 #pragma once
 #include "common.h"

@@ -31,8 +31,6 @@ SYMBOLS = {
     "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dss_mlp_k384_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "dss_mlp_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -223,34 +221,6 @@ def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu:
         _check(getattr(load_library(), entry)(_dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(out, "out"),
                                               m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
                                               _stream()), entry)
-    return out
-
-
-def mlp_k384_pack(fc1_weight: torch.Tensor, fc2_weight: torch.Tensor):
-    """``fc1.weight [1536, 384]``, ``fc2.weight [384, 1536]`` -> the operand order ``mlp_k384`` streams (same shapes and
-    dtype; once per layer)."""
-    assert tuple(fc1_weight.shape) == (1536, 384) and tuple(fc2_weight.shape) == (384, 1536)
-    assert fc1_weight.dtype == fc2_weight.dtype and fc1_weight.dtype in (torch.float16, torch.bfloat16)
-    p1, p2 = torch.empty_like(fc1_weight), torch.empty_like(fc2_weight)
-    _check(load_library().dss_mlp_k384_pack(_dev(fc1_weight, "fc1_weight"), _dev(fc2_weight, "fc2_weight"),
-                                            _dev(p1, "p1"), _dev(p2, "p2"), dtype_code(fc1_weight.dtype), _stream()),
-           "dss_mlp_k384_pack")
-    return p1, p2
-
-
-def mlp_k384(x: torch.Tensor, fc1_w_packed: torch.Tensor, fc1_b: torch.Tensor, fc2_w_packed: torch.Tensor,
-             fc2_b: torch.Tensor, planar: bool = False) -> torch.Tensor:
-    """DINO's Mlp ``fc2(GELU(fc1(x)))`` for ``x [..., 384]`` in one kernel (weights from ``mlp_k384_pack``).  Returns
-    ``[..., 384]`` or, with ``planar``, the DSS_PLANAR64 form ``[6, rows, 64]``."""
-    assert x.shape[-1] == 384 and tuple(fc1_w_packed.shape) == (1536, 384) and tuple(fc2_w_packed.shape) == (384, 1536)
-    assert x.dtype == fc1_w_packed.dtype == fc1_b.dtype == fc2_w_packed.dtype == fc2_b.dtype
-    m = x.numel() // 384
-    out = torch.empty((6, m, 64) if planar else x.shape, dtype=x.dtype, device=x.device)
-    with _timed("mlp_k384", m=m):
-        _check(load_library().dss_mlp_k384(_dev(x, "x"), _dev(fc1_w_packed, "fc1_w_packed"), _dev(fc1_b, "fc1_b"),
-                                           _dev(fc2_w_packed, "fc2_w_packed"), _dev(fc2_b, "fc2_b"), _dev(out, "out"),
-                                           m, PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype), _stream()),
-               "dss_mlp_k384")
     return out
 
 

@@ -109,9 +109,6 @@ class DinoViT:
         # (DSS_LINEAR_K384=1: qkv + proj only; 2, the default: also fc1 with the erf-GELU fused into its epilogue;
         #  3: additionally fc1+GELU of the D = 768 models, measured slower there)
         self.linear_k384 = int(os.environ.get("DSS_LINEAR_K384", "2") or 0)
-        # DSS_MLP_FUSED=1: fc1 -> GELU -> fc2 in one kernel (dss_mlp_k384, D = 384 only).  Parity-green but 7-13 %
-        # slower than the unfused pair in round 1 (mlp384.hip), hence opt-in.
-        self.mlp_fused = os.environ.get("DSS_MLP_FUSED", "0") not in ("0", "")
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -204,11 +201,6 @@ class DinoViT:
                 o = hip.attention(qkv, heads, self.scale)
                 pending = F.linear(o, blk["proj_w"], blk["proj_b"])
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
-            if self.mlp_fused and d == 384 and self.gelu == "erf":
-                if "fc2_wp" not in blk:
-                    blk["fc1_wp"], blk["fc2_wp"] = hip.mlp_k384_pack(blk["fc1_w"], blk["fc2_w"])
-                pending = hip.mlp_k384(hcur, blk["fc1_wp"], blk["fc1_b"], blk["fc2_wp"], blk["fc2_b"])
-                continue
             if kres_fc1:
                 f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)        # row-major: fc2 is a library GEMM
             elif self.gelu == "erf":

@@ -92,17 +92,6 @@ int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int
 int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
                     int dtype, void* stream);
 
-/* ---- a6: DINO's Mlp of the D = 384 models in one kernel: C = fc2(GELU(fc1(A))) ------------------------------------
- * (replaces  x = self.fc2(self.act(self.fc1(x)))  of DINO's Mlp; reached from extract/extract.py:94).
- * A [M, 384] row-major, b1 [1536], b2 [384], C [M, 384] (row-major or DSS_PLANAR64), all `dtype` (DSS_F16 / DSS_BF16);
- * fp32 accumulation, exact-erf GELU, hidden activations rounded to `dtype` exactly where the unfused pair rounds them.
- * W1_packed / W2_packed: fc1.weight [1536, 384] and fc2.weight [384, 1536] re-ordered once by dss_mlp_k384_pack
- * (same byte sizes) into the MFMA fragment order the kernel streams - in particular such that fc1's accumulator
- * registers are directly fc2's MFMA operand (mlp384.hip). */
-int dss_mlp_k384_pack(const void* W1, const void* W2, void* W1_packed, void* W2_packed, int dtype, void* stream);
-int dss_mlp_k384(const void* A, const void* W1_packed, const void* b1, const void* W2_packed, const void* b2, void* C,
-                 int M, int out_layout, int dtype, void* stream);
-
 /* ---- a10: row L2 normalisation -------------------------------------------------------------
  * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */
 int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream);

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""profiles/rNN_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/gpu_check.sh pmc.
+"""profiles/rNN_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 PMC passes of `scripts/gpu_r2.sh pmc`
+(one counter per pass; the per-kernel CSVs are written by scripts/rocpd_pmc_multi.py).
 
-    python scripts/make_pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_FETCH_SIZE.csv \
-        gpurun_out/pmc_WRITE_SIZE/pmc_WRITE_SIZE.csv gpurun_out/pmc_FETCH_SIZE/bench.json profiles/r01_pmc_traffic.json
+    python scripts/make_pmc_traffic.py profiles/r02_pmc_fetch.csv profiles/r02_pmc_write.csv \
+        gpurun_out/pmc_fetch/bench.json profiles/r02_pmc_traffic.json
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE is doubled per
 MI355X_MICROARCH.md section HBM (gfx950 counts 128-byte requests as 64 B; checked in the same run on a plain
@@ -13,9 +14,9 @@ import sys
 
 KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
     "linear_kres": "linear_kres_kernel",
-    "attention": "attn_fwd2_kernel",
+    "attention": "attn_fwd",
     "laplacian_eigs": "laplacian_eigs_kernel",
-    "affinity": "gram_split_kernel",
+    "affinity": "gram_",
     "layernorm": "layernorm_kernel",
     "normalize_rows_split": "normalize_rows_split_kernel",
     "torch_gelu (FETCH_SIZE calibration)": "GeluCUDAKernelImpl",
@@ -23,10 +24,13 @@ KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
 
 
 def load(path):
+    """kernel -> (dispatches, average counter value, average us); the counter is the last column."""
     rows = {}
     with open(path) as f:
-        for r in csv.DictReader(l for l in f if not l.startswith("#")):
-            rows[r["kernel"]] = (int(r["dispatches"]), float(r["avg_value"]), float(r["avg_us"]))
+        rd = csv.DictReader(l for l in f if not l.startswith("#"))
+        counter = rd.fieldnames[-1]
+        for r in rd:
+            rows[r["kernel"]] = (int(r["dispatches"]), float(r[counter]), float(r["avg_us"]))
     return rows
 
 

@@ -34,10 +34,9 @@ def test_vit_features_match_oracle(dtype, tol, h, w):
         assert rel < tol, rel
 
 
-@pytest.mark.parametrize("env", [{"DSS_MLP_FUSED": "1"}, {"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"},
-                                 {"DSS_LINEAR_K384": "3"}])
+@pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "3"}])
 def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
-    """The non-default ways through the ViT (fused Mlp kernel; library GEMMs only; K-resident qkv/proj only; the
+    """The non-default ways through the ViT (library GEMMs only; K-resident qkv/proj only; the
     K = 768 kernel forced for ViT-B) against the fp32 oracle ViT, same bar as the default path."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
