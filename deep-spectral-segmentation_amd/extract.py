@@ -42,7 +42,9 @@ if __package__ in (None, ""):  # executed as a script: make the package importab
     from dss_amd import extract_utils as utils
     from dss_amd import spectral
     from dss_amd.distributed import init_process_group, rank_world, local_device
+    from dss_amd import extract as _pkg   # worker processes resolve their entry points in the PACKAGE module
 else:
+    _pkg = sys.modules[__name__]
     from . import extract_utils as utils
     from . import spectral
     from .distributed import init_process_group, rank_world, local_device
@@ -52,6 +54,25 @@ _DTYPES = {"float16": torch.float16, "fp16": torch.float16, "f16": torch.float16
 
 
 _IO_THREADS = max(8, min(32, (os.cpu_count() or 8) // 2))
+
+
+class _spawn_without_main:
+    """``spawn`` children normally re-import the parent's ``__main__`` - a caller's script without an
+    ``if __name__ == "__main__"`` guard would then run again inside every I/O worker.  The workers here only need this
+    package (their entry points are ``dss_amd.extract`` functions), so ``__main__`` is hidden from multiprocessing while
+    they are started."""
+
+    def __enter__(self):
+        self.main = sys.modules.get("__main__")
+        self.saved = {a: getattr(self.main, a) for a in ("__file__", "__spec__") if hasattr(self.main, a)}
+        if "__file__" in self.saved:
+            del self.main.__file__
+        if self.main is not None:
+            self.main.__spec__ = None
+
+    def __exit__(self, *exc):
+        for a, v in self.saved.items():
+            setattr(self.main, a, v)
 
 
 def _bounded_map(pool: ThreadPoolExecutor, fn, items, window: int):
@@ -68,15 +89,27 @@ def _bounded_map(pool: ThreadPoolExecutor, fn, items, window: int):
 
 
 class _AsyncSaver:
-    """``torch.save`` off the critical path: files are written by a small thread pool while the GPU works on the
-    next batch (measured: serial saves of 1.4 MB feature files cap the CLI at ~120 images/s; threaded ~210);
-    ``close()`` waits for all of them and re-raises the first error."""
+    """``torch.save`` off the critical path.  Small runs: a thread pool (measured: serial saves of 1.4 MB feature files
+    cap the CLI at ~120 images/s; threads ~210 - pickling and the zip writer hold the GIL).  Large runs
+    (``processes > 0``): worker PROCESSES fed whole batches through shared memory (``submit_batch``), so the per-image
+    pickling runs in parallel; ``close()`` waits for everything and re-raises the first error."""
 
-    def __init__(self, threads: int = _IO_THREADS, max_pending: int = 1024):
+    def __init__(self, threads: int = _IO_THREADS, max_pending: int = 1024, processes: int = 0):
         self.pool = ThreadPoolExecutor(max_workers=threads)
         self.futures: List = []
         self.waited = 0
         self.max_pending = max_pending
+        self.procs, self.queue, self.errors = [], None, None
+        if processes > 0:
+            import torch.multiprocessing as mp
+
+            ctx = mp.get_context("spawn")      # never fork a process that holds a HIP context
+            self.queue, self.errors = ctx.Queue(maxsize=2 * processes), ctx.Queue()
+            self.procs = [ctx.Process(target=_pkg._save_worker, args=(self.queue, self.errors), daemon=True)
+                          for _ in range(processes)]
+            with _spawn_without_main():
+                for p in self.procs:
+                    p.start()
 
     def submit(self, obj, path: str):
         self.futures.append(self.pool.submit(torch.save, obj, path))
@@ -86,12 +119,135 @@ class _AsyncSaver:
                 f.result()
             self.waited = upto
 
+    def submit_batch(self, kind: str, tensors: Tuple[torch.Tensor, ...], items: List[tuple], chunk: int = 16):
+        """``items`` (one tuple per file, see ``_SAVE_BUILDERS[kind]``) index into the batch ``tensors`` (host tensors;
+        moved to shared memory once per batch).  Without worker processes the files are built here and saved by threads."""
+        if not self.procs:
+            for it in items:
+                self.submit(*_SAVE_BUILDERS[kind](tensors, it))
+            return
+        tensors = tuple(t if t.is_shared() else t.share_memory_() for t in tensors)
+        for s in range(0, len(items), chunk):
+            self._put((kind, tensors, items[s:s + chunk]))
+
+    def _put(self, job):
+        import queue
+
+        while True:   # blocks while the workers are behind - but never on workers that are gone
+            try:
+                return self.queue.put(job, timeout=5)
+            except queue.Full:
+                if not all(p.is_alive() for p in self.procs):
+                    raise RuntimeError("a saver process died") from None
+
     def close(self):
         for f in self.futures:
             f.result()
         self.futures.clear()
         self.waited = 0
         self.pool.shutdown()
+        if self.procs:
+            for _ in self.procs:
+                self._put(None)
+            for p in self.procs:
+                p.join()
+            failed = [p.exitcode for p in self.procs if p.exitcode != 0]
+            errs = []
+            while not self.errors.empty():
+                errs.append(self.errors.get())
+            self.procs = []
+            if errs or failed:
+                raise RuntimeError(f"saver process failed: {errs[:3] or failed}")
+
+
+def _build_feature_file(tensors, item):
+    (k,), (j, idx, file, model_name, patch_size, shape, out) = tensors, item
+    return _feature_dict(k[j:j + 1].clone(), idx, file, model_name, patch_size, shape), out
+
+
+def _build_eig_file(tensors, item):
+    # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32; the 'affinity' branch
+    # stores its eigenvalues as a raw numpy array (:171,243) - kept, consumers load it that way
+    (ev, vec), (j, out, problem) = tensors, item
+    vals = ev[j].clone()
+    return {"eigenvalues": vals.numpy() if problem == "affinity" else vals, "eigenvectors": vec[j].clone()}, out
+
+
+_SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file}
+
+
+def _save_worker(queue, errors):
+    torch.set_num_threads(1)
+    while True:
+        job = queue.get()
+        if job is None:
+            return
+        kind, tensors, items = job
+        try:
+            for it in items:
+                torch.save(*_SAVE_BUILDERS[kind](tensors, it))
+        except BaseException as e:  # reported by close() in the parent
+            errors.put(f"{type(e).__name__}: {e}")
+        del tensors, job
+
+
+def _load_feature_chunk(args):
+    """Worker side of the ``extract_eigs`` loader: read a chunk of feature files, return ``[(meta dicts, features
+    [n, N, D] f32)]`` with one entry per distinct feature shape - the big tensors travel back through shared memory."""
+    files, which_features = args
+    torch.set_num_threads(1)
+    groups: Dict[Tuple[int, ...], Tuple[list, list]] = {}
+    for f in files:
+        data_dict, feats = _load_features(str(f), which_features)
+        meta = {k: v for k, v in data_dict.items() if not torch.is_tensor(v) or v.numel() <= 16}
+        metas, tensors = groups.setdefault(tuple(feats.shape), ([], []))
+        metas.append(meta), tensors.append(feats)
+    return [(metas, torch.stack(tensors)) for metas, tensors in groups.values()]
+
+
+def _iter_features(files, which_features: str, processes: int, window: int):
+    """Yields ``(data_dict without the features, features [N, D] f32)`` for every file of ``files``: loaded by a thread
+    pool (small runs) or by worker processes in chunks of 32 files with at most ``2 * processes`` chunks in flight."""
+    if processes <= 0:
+        with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
+            yield from _bounded_map(pool, lambda f: _load_features(str(f), which_features), files, window)
+        return
+    import torch.multiprocessing as mp
+    from collections import deque
+
+    chunks = [(files[s:s + 32], which_features) for s in range(0, len(files), 32)]
+    with _spawn_without_main():
+        pool = mp.get_context("spawn").Pool(processes)
+    with pool:
+        pending = deque()
+        for c in chunks:
+            pending.append(pool.apply_async(_pkg._load_feature_chunk, (c,)))
+            while len(pending) >= 2 * processes:
+                for metas, stacked in pending.popleft().get(timeout=600):   # a lost worker must not hang the run
+                    yield from zip(metas, stacked)
+        while pending:
+            for metas, stacked in pending.popleft().get(timeout=600):
+                yield from zip(metas, stacked)
+
+
+def _shm_free_bytes() -> int:
+    try:
+        st = os.statvfs("/dev/shm")
+        return st.f_bavail * st.f_frsize
+    except OSError:
+        return 0
+
+
+def _io_processes(n_items: int, most: int = 16) -> int:
+    """Worker processes for the per-image file I/O of a run of ``n_items`` files on this rank: none for small runs (a
+    spawned interpreter costs ~2 s), otherwise a share of the host cores, at most ``most`` (``$DSS_IO_PROCESSES``
+    overrides)."""
+    if os.environ.get("DSS_IO_PROCESSES"):
+        return int(os.environ["DSS_IO_PROCESSES"])
+    if n_items < 512 or _shm_free_bytes() < (8 << 30):   # batches travel through /dev/shm: needs room
+        return 0
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    return max(2, min(most, (os.cpu_count() or 8) // (4 * max(1, local))))
 
 
 def _barrier():
@@ -154,16 +310,20 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
             continue
         todo.append((i, out))
 
-    saver = _AsyncSaver()
+    saver = _AsyncSaver(processes=_io_processes(len(todo)))
 
     def flush(batch: List[Tuple[int, Path, torch.Tensor, str]]):
         if not batch:
             return
         imgs = torch.stack([b[2] for b in batch]).to(device, non_blocking=True)
-        k = model.extract_k(imgs, which_block=which_block).cpu()
-        h, w = imgs.shape[1], imgs.shape[2]
-        for j, (idx, out, _, file) in enumerate(batch):
-            saver.submit(_feature_dict(k[j:j + 1].clone(), idx, file, model_name, patch_size, (1, 3, h, w)), str(out))
+        k_dev = model.extract_k(imgs, which_block=which_block)
+        k = torch.empty(k_dev.shape, dtype=k_dev.dtype)
+        if saver.procs:
+            k.share_memory_()          # D2H straight into the segment the saver processes map
+        k.copy_(k_dev)
+        shape = (1, 3, int(imgs.shape[1]), int(imgs.shape[2]))
+        saver.submit_batch("features", (k,), [(j, idx, file, model_name, patch_size, shape, str(out))
+                                              for j, (idx, out, _, file) in enumerate(batch)])
         batch.clear()
 
     # Real datasets (VOC) mix image sizes: bucket by shape so every ViT launch is a full same-shape batch.  At most
@@ -250,7 +410,11 @@ def _lr_grid(data_dict: dict, image_downsample_factor: Optional[int]) -> Tuple[i
 def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: bool, threshold_at_zero: bool,
                    device: torch.device, saver: Optional["_AsyncSaver"] = None, problem: str = "laplacian",
                    upsample=None, color=None, color_items: Optional[List[Tuple[str, Tuple[int, int]]]] = None):
-    feats = torch.stack([f for _, f in items]).to(device, non_blocking=True)
+    # straight from wherever the loader left each file's features (a shared-memory segment when worker processes read
+    # them) into the device batch: no host-side torch.stack pass over 1.4 MB per image
+    feats = torch.empty((len(items),) + tuple(items[0][1].shape), dtype=torch.float32, device=device)
+    for j, (_, f) in enumerate(items):
+        feats[j].copy_(f, non_blocking=True)
     if color is not None:
         # extract.py:191-218 with a colour term: W_comb = W_feat / max(W_feat) + lambda * W_color, dense on the device
         # (the matrix is no longer a Gram matrix of the features), packed into the solver's tile layout, same kernel.
@@ -274,15 +438,11 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
     if bad:
         print(f"[dss] WARNING: eigensolver did not converge for {[items[j][0] for j in bad]} (saved as is)")
     ev, vec = ev.cpu(), vec.cpu()
-    for j, (output_file, _) in enumerate(items):
-        # schema of extract/extract.py:235,243-244: eigenvalues [K] f32, eigenvectors [K, N] f32; the 'affinity'
-        # branch stores its eigenvalues as a raw numpy array (:171,243) - kept, consumers load it that way
-        vals = ev[j].clone()
-        obj = {"eigenvalues": vals.numpy() if problem == "affinity" else vals, "eigenvectors": vec[j].clone()}
-        if saver is None:
-            torch.save(obj, output_file)
-        else:
-            saver.submit(obj, output_file)
+    if saver is None:
+        for j, (output_file, _) in enumerate(items):
+            torch.save(*_build_eig_file((ev, vec), (j, output_file, problem)))
+    else:
+        saver.submit_batch("eigs", (ev, vec), [(j, output_file, problem) for j, (output_file, _) in enumerate(items)])
 
 
 def _extract_eig(inp: Tuple[int, str], K: int, images_root: str, output_dir: str,
@@ -327,10 +487,6 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     files = sorted(Path(features_dir).iterdir())
     mine = files[rank::world]
 
-    def load(f):
-        data_dict, feats = _load_features(str(f), which_features)
-        return data_dict, feats
-
     color = _color_spec(which_matrix, which_color_matrix, image_color_lambda, images_root)
     pending: Dict[Tuple, List[Tuple[str, torch.Tensor]]] = {}
     pending_ids: Dict[Tuple, List[Tuple[str, Tuple[int, int]]]] = {}
@@ -342,28 +498,29 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
 
     bs = max(1, int(batch_size))
     n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
-    saver = _AsyncSaver()
-    with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
-        for data_dict, feats in _bounded_map(pool, load, mine, 4 * max(1, int(batch_size))):
-            image_id = data_dict["file"][:-4]
-            output_file = str(Path(output_dir) / f"{image_id}.pth")
-            if Path(output_file).is_file():
-                print(f"Skipping existing file {str(output_file)}")
-                continue
-            problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
-                                         data_dict["patch_size"])
-            utils.get_image_sizes(data_dict)
-            up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
-            key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
-            pending.setdefault(key, []).append((output_file, feats))
-            pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
-            problems[key] = problem
-            n_pending += 1
-            if len(pending[key]) < bs and n_pending >= max_pending:
-                key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
-            if len(pending[key]) >= bs or n_pending >= max_pending:
-                n_pending -= len(pending[key])
-                run(key)
+    # torch.load of a 1.4 MB feature file costs ~0.6 ms and torch.save of an 18 KB eigen file less: few workers do
+    nproc = _io_processes(len(mine), most=8)
+    saver = _AsyncSaver(processes=min(nproc, 4))
+    for data_dict, feats in _iter_features(mine, which_features, nproc, 4 * bs):
+        image_id = data_dict["file"][:-4]
+        output_file = str(Path(output_dir) / f"{image_id}.pth")
+        if Path(output_file).is_file():
+            print(f"Skipping existing file {str(output_file)}")
+            continue
+        problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
+                                     data_dict["patch_size"])
+        utils.get_image_sizes(data_dict)
+        up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
+        key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
+        pending.setdefault(key, []).append((output_file, feats))
+        pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
+        problems[key] = problem
+        n_pending += 1
+        if len(pending[key]) < bs and n_pending >= max_pending:
+            key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
+        if len(pending[key]) >= bs or n_pending >= max_pending:
+            n_pending -= len(pending[key])
+            run(key)
     for key in list(pending):
         run(key)
     saver.close()

@@ -16,6 +16,8 @@ for STAGE in "$@"; do
     bench_dataset) timeout 900 python bench.py --dataset 10000 --cpu-images 0 > gpurun_out/bench_dataset.json 2> gpurun_out/bench_dataset.err; echo "bench_dataset exit: $?"; tail -3 gpurun_out/bench_dataset.err; cat gpurun_out/bench_dataset.json;;
     bench_spawn2) DSS_DIST_BACKEND=nccl timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 --cpu-images 0 > gpurun_out/bench_spawn2.json 2> gpurun_out/bench_spawn2.err; echo "bench_spawn2 exit: $? (expected to fail on a 1-GPU box unless both ranks share the GPU)"; tail -5 gpurun_out/bench_spawn2.err; cat gpurun_out/bench_spawn2.json;;
     bench_spawn2_gloo) DSS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 --cpu-images 0 --companion-steps 0 > gpurun_out/bench_spawn2_gloo.json 2> gpurun_out/bench_spawn2_gloo.err; echo "bench_spawn2_gloo exit: $? (two ranks sharing the one GPU, host-side collectives)"; tail -5 gpurun_out/bench_spawn2_gloo.err; cat gpurun_out/bench_spawn2_gloo.json;;
+    cli) timeout 240 python scripts/cli_throughput.py ${CLI_N:-4096} > gpurun_out/cli.log 2>&1; echo "cli exit $?"; grep "images/s" gpurun_out/cli.log;;
+    cli_threads) DSS_IO_PROCESSES=0 timeout 300 python scripts/cli_throughput.py ${CLI_N:-4096} > gpurun_out/cli_threads.log 2>&1; echo "cli_threads exit $?"; grep "images/s" gpurun_out/cli_threads.log;;
     prof)   # per-kernel time of the bench command (rocprofv3 kernel trace); the summary is copied to profiles/ by hand
       REPO_DIR=$PWD; rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO_DIR/gpurun_out/prof -o bench -- python $REPO_DIR/bench.py --steps 2 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/prof/bench.json 2> $REPO_DIR/gpurun_out/prof/bench.err)

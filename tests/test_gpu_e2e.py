@@ -34,6 +34,32 @@ def test_vit_features_match_oracle(dtype, tol, h, w):
         assert rel < tol, rel
 
 
+def test_patch_indexing_on_the_hip_path():
+    """Row n of the features is patch (n // W_p, n % W_p), CLS dropped (extract.py:96-98; the reference-side contract
+    is tests/golden/index_probe.npz): with the position embedding zeroed the ViT is equivariant to a permutation of
+    the patches, so swapping the pixels of two patches must swap exactly those two feature rows - through the real
+    kernels (patchify, attention with its CLS token, planar layouts, K slice)."""
+    sd = synthetic.synthetic_state_dict("dino_vits16", 11, 0.05)
+    sd["pos_embed"] = torch.zeros_like(sd["pos_embed"])
+    model = DinoViT("dino_vits16", sd, DEV, torch.float16)
+    h, w, p = 80, 112, 16                         # 5 x 7 patches, plus 3 / 5 pixels that the crop drops
+    img = synthetic.synthetic_image(77, h + 3, w + 5)
+    (r1, c1), (r2, c2) = (1, 5), (3, 2)
+    swapped = img.copy()
+    swapped[r1 * p:(r1 + 1) * p, c1 * p:(c1 + 1) * p] = img[r2 * p:(r2 + 1) * p, c2 * p:(c2 + 1) * p]
+    swapped[r2 * p:(r2 + 1) * p, c2 * p:(c2 + 1) * p] = img[r1 * p:(r1 + 1) * p, c1 * p:(c1 + 1) * p]
+    k = model.extract_k(torch.from_numpy(np.stack([img, swapped])).to(DEV)).cpu()
+    assert k.shape == (2, 35, 384)
+    wp = w // p
+    perm = list(range(35))
+    perm[r1 * wp + c1], perm[r2 * wp + c2] = r2 * wp + c2, r1 * wp + c1
+    scale = k[0].abs().max().item()
+    assert (k[1] - k[0][perm]).abs().max().item() < 2e-3 * scale           # same tokens, summed in another order
+    assert (k[1] - k[0]).abs().max().item() > 0.05 * scale                 # ... and the swap is visible at all
+    moved = ((k[1] - k[0]).abs().amax(1) > 0.02 * scale).nonzero().flatten().tolist()
+    assert set(moved) >= {r1 * wp + c1, r2 * wp + c2}
+
+
 @pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "3"}])
 def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
     """The non-default ways through the ViT (library GEMMs only; K-resident qkv/proj only; the

@@ -234,3 +234,36 @@ def test_dataset_applies_exif_orientation_like_cv2(tmp_path):
     plain, rot = ds[0][0], ds[1][0]
     assert tuple(plain.shape) == (20, 30, 3) and tuple(rot.shape) == (30, 20, 3)
     assert np.array_equal(rot.numpy(), np.rot90(arr, k=-1))
+
+
+def test_file_io_worker_processes_round_trip(tmp_path):
+    """Large CLI runs hand whole batches to saver / loader PROCESSES through shared memory (extract._AsyncSaver,
+    extract._iter_features): same files as the in-process path, errors surfaced by close()."""
+    k = torch.randn(5, 12, 8)
+    items = [(j, 100 + j, f"im_{j}.jpg", "dino_vits16", 16, (1, 3, 48, 64), str(tmp_path / f"im_{j}.pth")) for j in range(5)]
+    saver = extract._AsyncSaver(processes=2)
+    saver.submit_batch("features", (k.clone(),), items, chunk=2)
+    ev, vec = torch.randn(5, 3), torch.randn(5, 3, 12)
+    (tmp_path / "e").mkdir()
+    saver.submit_batch("eigs", (ev.clone(), vec.clone()), [(j, str(tmp_path / "e" / f"im_{j}.pth"), "laplacian" if j else "affinity")
+                                                           for j in range(5)])
+    saver.close()
+    for j in range(5):
+        d = torch.load(tmp_path / f"im_{j}.pth", weights_only=True)
+        assert torch.equal(d["k"], k[j:j + 1]) and int(d["indices"]) == 100 + j and d["id"] == f"im_{j}"
+        assert d["k"].untyped_storage().nbytes() == 12 * 8 * 4          # one image per file, not the whole batch
+        e = torch.load(tmp_path / "e" / f"im_{j}.pth", weights_only=False)
+        assert torch.equal(e["eigenvectors"], vec[j]) and np.array_equal(np.asarray(e["eigenvalues"]), ev[j].numpy())
+        assert isinstance(e["eigenvalues"], np.ndarray) == (j == 0)
+    # mixed shapes through the loader processes, every file exactly once
+    torch.save({"k": torch.randn(1, 7, 8), "file": "odd.jpg", "id": "odd", "patch_size": 16, "shape": (1, 3, 16, 112),
+                "indices": torch.tensor(9), "model_name": "m"}, tmp_path / "zz_odd.pth")
+    files = sorted(p for p in tmp_path.iterdir() if p.suffix == ".pth")
+    got = {d["id"]: f for d, f in extract._iter_features(files, "k", 2, 8)}
+    ref = {d["id"]: f for d, f in extract._iter_features(files, "k", 0, 8)}
+    assert set(got) == set(ref) == {f"im_{j}" for j in range(5)} | {"odd"}
+    assert all(torch.equal(got[i], ref[i]) for i in got) and got["odd"].shape == (7, 8)
+    bad = extract._AsyncSaver(processes=1)
+    bad.submit_batch("features", (k.clone(),), [(0, 0, "x.jpg", "m", 16, (1, 3, 4, 4), str(tmp_path / "no_dir" / "x.pth"))])
+    with pytest.raises(RuntimeError):
+        bad.close()
