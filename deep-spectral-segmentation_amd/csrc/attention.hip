@@ -136,8 +136,11 @@ __device__ __forceinline__ float half_pair_sum(float x) {
 // between the end of a workgroup (its output stores drain before its registers and LDS are released) and the start of
 // its successor, 16 % of a 40 us workgroup.  Tried against that and measured slower: workgroups that walk several work
 // items (2 / 4 / 8 / all of a CU slot's ~14: +1 ... +20 %; item times vary 23-74 us with what the neighbours are doing, so
-// static walks lose to the hardware dispatcher what they save on the gap), a three-tile LDS ring with the score MFMAs of
-// the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower).
+// static walks lose to the hardware dispatcher what they save on the gap), a PERSISTENT grid of two workgroups per CU
+// that draw items dynamically from per-XCD ticket counters, the next ticket fetched while the current item runs
+// (bit-identical results; 540 vs 535 us at T = 901, 105 vs 49 us at T = 197 - the "gap" is the item's own prologue and
+// drain, not dispatch latency, and only a second resident workgroup hides it), a three-tile LDS ring with the score
+// MFMAs of the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower).
 template <class T>
 __global__ __launch_bounds__(512, 4) void attn_fwd4_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
                                                            int heads, int nb, int nqb, float scale_log2,
