@@ -140,7 +140,14 @@ __device__ __forceinline__ float half_pair_sum(float x) {
 // that draw items dynamically from per-XCD ticket counters, the next ticket fetched while the current item runs
 // (bit-identical results; 540 vs 535 us at T = 901, 105 vs 49 us at T = 197 - the "gap" is the item's own prologue and
 // drain, not dispatch latency, and only a second resident workgroup hides it), a three-tile LDS ring with the score
-// MFMAs of the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower).
+// MFMAs of the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower), and the same software
+// pipeline done properly at two waves per SIMD - 64 queries per wave as two independent 32-query tiles A / B, per 32 keys
+// the steps {S_B = K.Q_B, O_B += V.P_B || softmax A} and {O_A += V.P_A, S_A(next) = K.Q_A || softmax B} with the
+// fragment reads of the next step issued first, every K / V^T fragment feeding two MFMAs, a 3-deep LDS ring with one
+// mid-tile barrier; 250 VGPRs, no spills, hipcc interleaves each step's 8 MFMAs with its ~45 VALU instructions
+// (sched_group_barrier), results bit-identical to this kernel: 588 vs 571 us on the same box.  Neither pipe is
+// saturated in either kernel (a SIMD retires one instruction per ~10 cycles); what is left needs instruction-level
+// control of issue and dependency stalls that the compiler does not give.
 template <class T>
 __global__ __launch_bounds__(512, 4) void attn_fwd4_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
                                                            int heads, int nb, int nqb, float scale_log2,

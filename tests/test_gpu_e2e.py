@@ -149,6 +149,35 @@ def test_config3_vitb8_480_k15_end_to_end():
                    d=build_w64(kr[0].numpy())[1], ext=ext)
 
 
+@pytest.mark.timeout(900)
+def test_config5_vitb8_mixed_sizes_k20_through_the_cli(tmp_path):
+    """BASELINE config 5's single-GPU content: dino_vitb8, MIXED image sizes in the 320-640 px range (non-multiples of 8
+    included), K=20, f16-operand features + fp32 eigensolve, through the two CLI stages (shape buckets, per-image B=1
+    files), each image against the whole CPU oracle path.  (The 8-GPU leg adds only the mixed-N gather:
+    tests/test_distributed_cpu.py.)"""
+    specs = [("c5_a.png", 61, 320, 404), ("c5_b.png", 62, 411, 336), ("c5_c.png", 63, 320, 404), ("c5_d.png", 64, 352, 480)]
+    _write_images(tmp_path / "images", specs)
+    (tmp_path / "images.txt").write_text("\n".join(s[0] for s in specs) + "\n")
+    extract.main(["extract_features", "--images_list", str(tmp_path / "images.txt"), "--images_root",
+                  str(tmp_path / "images"), "--output_dir", str(tmp_path / "feat"), "--model_name", "dino_vitb8",
+                  "--batch_size", "2", "--synthetic_weights", "0"])
+    extract.main(["extract_eigs", "--images_root", str(tmp_path / "images"), "--features_dir", str(tmp_path / "feat"),
+                  "--output_dir", str(tmp_path / "eigs"), "--K", "20", "--batch_size", "2"])
+    ref = vit_ref.build_ref_vit("dino_vitb8", synthetic.synthetic_state_dict("dino_vitb8", 0))
+    for name, idx, h, w in specs[1:]:            # a, c share a shape (one launch); check b, c, d against the oracle
+        f = torch.load(tmp_path / "feat" / (name[:-4] + ".pth"), weights_only=True)
+        e = torch.load(tmp_path / "eigs" / (name[:-4] + ".pth"), weights_only=True)
+        n = (h // 8) * (w // 8)
+        assert f["shape"] == (1, 3, h, w) and tuple(f["k"].shape) == (1, n, 768) and tuple(e["eigenvectors"].shape) == (20, n)
+        kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(synthetic.synthetic_image(idx, h, w)))
+        assert ((f["k"] - kr).norm() / kr.norm()).item() < 4e-3
+        lam, v, ext, draws = spectral_ref.ref_laplacian_eigs_ext(kr, 20)
+        report = []
+        check_eigs(e["eigenvectors"].numpy(), e["eigenvalues"].numpy(), v.numpy(), lam.numpy(), what=f"config5 {name}",
+                   lam_tol=1e-3, d=build_w64(kr[0].numpy())[1], ext=ext, report=report)
+        print(f"[config5] {name} N={n}: oracle draws={draws}; clusters: {[r for r in report if r['kind'] != 'isolated']}")
+
+
 def test_cli_buckets_mixed_shapes(tmp_path):
     """Interleaved image sizes: the CLI buckets by shape; every image still gets its own correct B=1 file."""
     specs = [(f"m_{i:02d}.png", 50 + i, (96, 128) if i % 2 else (128, 96)) for i in range(6)]
