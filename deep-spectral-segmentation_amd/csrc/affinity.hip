@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
 //     goldens by <= 3e-6 in cosine (tests/test_gpu_kernels.py) - the 1e-4 budget is untouched;
 //   * same tiling / packed symmetric output / XCD-aware block order as gram_split_kernel.
 // LDS: f16 panels [128][32 + 8] (80-byte rows: ds_read_b128 conflict-free) for A and B, + the 256 inverse norms.
+// Measured and rejected: 64-column stages in a DOUBLE-buffered LDS image with one barrier per stage (16 MFMAs per wave
+// between barriers instead of 8 between two; 220 VGPRs, two workgroups per CU): 2.40 ms vs 2.30 ms per 2030 images - the
+// third resident workgroup hides more latency than the second barrier costs.
 static constexpr int FK = 32;        // feature columns per stage
 static constexpr int FLD = FK + 8;   // halves per LDS row (80 B)
 
