@@ -388,14 +388,25 @@ def main():
     from dss_amd.vit import setup_gemm_tuning
     setup_gemm_tuning(tune_new_shapes=True)   # warm-up may pick GEMM solutions for shapes missing from the shipped table
     t_warm = time.perf_counter()
-    n_warm = 0
+    n_warm, warm = 0, None
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
         feeder.prefetch(n_warm)
-        step(model, feeder.get(n_warm), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+        warm = step(model, feeder.get(n_warm), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
         feeder.release(n_warm)
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
+    if world > 1 and warm is None:   # --warmup 0: the collection warm-up below still needs one step's results
+        feeder.prefetch(0)
+        warm = step(model, feeder.get(0), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+        feeder.release(0)
+    if world > 1:
+        # warm the COLLECTION path too: RCCL sets up its point-to-point channels (one per peer) on first use - seconds,
+        # not part of any steady state - so one full-size collection of a warm-up step's results runs before the clock
+        ids = torch.arange(warm[0].shape[0], device=dev, dtype=torch.int64) * world + rank
+        distributed.gather_records_to_root(*distributed.pack_records(ids, warm[0], warm[1]))
+        del ids
+    del warm
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
