@@ -12,10 +12,13 @@
 //     buffered) by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  The LDS image is
 //     FRAGMENT-MAJOR - 16-byte piece 64 s + lane is exactly the operand lane `lane` needs at k-step s - so the
 //     compute loop reads ds_read_b128 at 16 * lane + 1024 * s: conflict-free, one address register.
-//   * 8 waves per workgroup in two groups that PING-PONG: while group X issues the 48 MFMAs of a chunk (alone on the
-//     matrix pipe, fragments prefetched 2 k-steps ahead), group Y runs the epilogue of its previous chunk (VALU GELU,
-//     LDS transpose, global stores), then they swap.  Epilogue and MFMA phases overlap by construction; two
-//     independent workgroups per CU were measured to run in lockstep instead (matrix pipe idle in every epilogue).
+//   * 8 waves per workgroup (two per SIMD), all on the same chunk: 50 MFMAs (fragments prefetched 2 k-steps ahead),
+//     then the chunk's epilogue (VALU GELU, LDS transpose, global stores), one barrier per chunk.  The two waves of a
+//     SIMD fill each other's MFMA issue gaps (one wave alone reaches ~50 % of the pipe: LDS latency behind a 2-step
+//     prefetch) and drift apart enough to overlap one's epilogue with the other's MFMAs.  Rounds 1-2 ran the two
+//     4-wave groups as a PING-PONG pair instead (one group multiplies while the other finishes its previous chunk, two
+//     barriers per chunk): same results bit for bit, but qkv 267 -> 227 us, proj 99 -> 94, fc1+GELU 469 -> 400 without it
+//     (same-process A/B, scripts/debug/linear_ab.py) - a lone MFMA wave per SIMD was the bottleneck, not the epilogue.
 //   * the product is D[col][row] = W_chunk . A^T, so a lane owns token rows; the wave transposes its 64 x 64 output
 //     tile (two chunks) through a private 8 KB LDS patch and stores FULL 128-byte lines, 8 rows per instruction.
 //     Measured for qkv: 8-byte pieces 404 us, 64-byte half lines 310 us, full lines 268 us (same MFMA loop).
@@ -31,7 +34,7 @@
 namespace dss {
 
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
-static constexpr int LWAVES = 8;          // two ping-pong groups of 4
+static constexpr int LWAVES = 8;          // two per SIMD
 static constexpr int LTHREADS = 64 * LWAVES;
 static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
 
@@ -61,7 +64,6 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
-  const bool group_x = wave < LWAVES / 2;
   const int mrem = M - blockIdx.x * LBM;                   // rows of this workgroup that exist (> 0)
   const int rloc = wave * Cfg::ROWS_WAVE;                  // this wave's first row inside the workgroup
   const bool block_full = mrem >= LBM;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
     }
   };
   auto wait_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  // phase barrier WITHOUT the release fence of __syncthreads(): that fence makes the compiler drain vmcnt to 0 (the
+  // chunk barrier WITHOUT the release fence of __syncthreads(): that fence makes the compiler drain vmcnt to 0 (the
   // tile stores!) in front of every barrier.  Nothing crosses waves through memory inside the loop except the W
   // chunks, whose arrival is awaited explicitly (wait_dma) by the issuing waves.
   auto phase_barrier = [&]() {
@@ -215,31 +217,18 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
     }
   };
 
-  // ---- ping-pong over the chunks.  Phase 2c: X multiplies chunk c, Y finishes chunk c-1; phase 2c+1: swapped.
-  //      Chunk c+1 is DMA'd into the other buffer during phase 2c (last read in phase 2c-1) and awaited (wait_dma)
-  //      before the barrier that ends phase 2c+1.
+  // ---- the chunks.  Chunk c + 1 is DMA'd into the other buffer at the start of chunk c's MFMA phase (that buffer was
+  //      last read in chunk c - 1, behind the barrier that ended it) and awaited (wait_dma) before the barrier that ends
+  //      chunk c.
   const int nchunks = N / LBN;
   stage(0);
   wait_vm();
   __syncthreads();
-  if (group_x) {
-    for (int c = 0; c < nchunks; ++c) {
-      mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
-      phase_barrier();
-      epilogue(c);
-      wait_dma(c);
-      phase_barrier();
-    }
-  } else {
-    for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) stage(c + 1);
-      if (c > 0) epilogue(c - 1);
-      phase_barrier();
-      mfma_phase(c, -1);
-      wait_dma(c > 0 ? c - 1 : 0);
-      phase_barrier();
-    }
-    epilogue(nchunks - 1);
+  for (int c = 0; c < nchunks; ++c) {
+    mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
+    epilogue(c);
+    wait_dma(c);
+    phase_barrier();
   }
 }
 
