@@ -7,7 +7,7 @@ raised.  Tensors are passed as raw device pointers (``tensor.data_ptr()``), the 
 from __future__ import annotations
 
 import ctypes
-from ctypes import c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 from pathlib import Path
 from typing import Optional
 

@@ -5,7 +5,6 @@ CPU tests: multi-region segmentation, boxes, eigensegment -> box (host-side book
 GPU tests (`-m gpu`): colour-affinity fusion through the Lanczos kernel, box-crop CLS features through the ViT kernels,
 the inline localization eigenvectors."""
 import inspect
-import io
 import json
 from pathlib import Path
 
