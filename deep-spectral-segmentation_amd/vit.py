@@ -106,8 +106,8 @@ class DinoViT:
         self.gelu = gelu
         # qkv / attn.proj of the D = 384 / 768 models on the K-resident kernel (dss_linear_k384/_k768), planar outputs that
         # the attention and LayerNorm kernels read in place; DSS_LINEAR_K384=0 keeps the library GEMMs (A/B switch)
-        # (DSS_LINEAR_K384=1: qkv + proj only; 2, the default: also fc1 with the erf-GELU fused into its epilogue;
-        #  3: additionally fc1+GELU of the D = 768 models, measured slower there)
+        # (DSS_LINEAR_K384=1: qkv + proj of the D = 384 models only; 2, the default: also fc1 with the erf-GELU fused into
+        #  its epilogue, for D = 384 and D = 768)
         self.linear_k384 = int(os.environ.get("DSS_LINEAR_K384", "2") or 0)
         d = self.embed_dim
         sd = state_dict
@@ -181,12 +181,12 @@ class DinoViT:
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
         # K-resident Linear kernel: at D = 384 it beats the library GEMM on qkv, proj and fc1+GELU.  At D = 768 (one
-        # row tile per wave: every W fragment feeds one MFMA instead of two) the library wins on qkv / proj (916 vs
-        # 787 TF/s) and the fused fc1+GELU, 9 % faster in isolation, is 2.5 % slower end to end on dino_vitb8: there the
-        # kernel (dss_linear_k768) is only used when forced with DSS_LINEAR_K384=3.
+        # row tile per wave: every W fragment feeds one MFMA instead of two) the library wins on qkv / proj (888-932 vs
+        # 740-771 TF/s), but fc1 with the erf-GELU fused (dss_linear_k768: 376-390 us against 488 us for the library GEMM
+        # + a separate GELU pass at 16 x 3601 tokens) wins end to end too: dino_vitb8 / C3 689-696 -> 704 images/s on
+        # the same box.
         k384 = self.linear_k384 and d == 384
-        kres_fc1 = self.gelu == "erf" and ((self.linear_k384 >= 2 and d == 384) or
-                                           (self.linear_k384 >= 3 and d in hip.LINEAR_KRES_WIDTHS))
+        kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
         for i in range(nblocks):
             blk = self.blocks[i]
             hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)

@@ -60,13 +60,15 @@ def test_patch_indexing_on_the_hip_path():
     assert set(moved) >= {r1 * wp + c1, r2 * wp + c2}
 
 
-@pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "3"}])
+@pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "0", "model": "dino_vitb16"},
+                                 {"DSS_LINEAR_K384": "2", "model": "dino_vitb16"}])
 def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
-    """The non-default ways through the ViT (library GEMMs only; K-resident qkv/proj only; the
-    K = 768 kernel forced for ViT-B) against the fp32 oracle ViT, same bar as the default path."""
+    """The ways through the ViT's Linear layers (library GEMMs only; K-resident qkv/proj only; ViT-B with and without
+    the fused fc1+GELU kernel at K = 768) against the fp32 oracle ViT, same bar as the default path."""
+    env = dict(env)
+    name = env.pop("model", "dino_vits16")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    name = "dino_vitb16" if env.get("DSS_LINEAR_K384") == "3" else "dino_vits16"
     model, ref = _models(name, 7, 0.05, torch.float16)
     imgs = np.stack([synthetic.synthetic_image(20 + i, 100, 130) for i in range(2)])
     k = model.extract_k(torch.from_numpy(imgs).to(DEV)).cpu()
