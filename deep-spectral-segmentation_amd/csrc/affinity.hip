@@ -55,6 +55,38 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 static constexpr int GB = 128;  // block tile (rows and cols)
+
+// Index `rem` of a block inside one image's upper block triangle (nbk x nbk blocks of GB rows, bj >= bi) -> (bi, bj),
+// enumerated in SUPER-TILES of GST x GST blocks: the workgroups of an image that run at the same time (consecutive
+// indices on one XCD) then touch ~2 GST panels per GST^2 blocks instead of a whole block row's worth.  At N = 900 an
+// image's features fit an XCD's L2 either way; at N = 3600, D = 768 (11 MB per image) the plain row-major order re-read
+// its panels 5.8x through the fabric (profiles/r02_c3_pmc_traffic.json).  All-scalar arithmetic, <= ~40 iterations.
+static constexpr int GST = 4;
+__device__ __forceinline__ void gram_block_of(int rem, int nbk, int& bi, int& bj) {
+  const int ns = (nbk + GST - 1) / GST;
+  for (int si = 0; si < ns; ++si) {
+    const int r0 = si * GST, r1 = min(r0 + GST, nbk);
+    for (int sj = si; sj < ns; ++sj) {
+      const int c0 = sj * GST, c1 = min(c0 + GST, nbk);
+      const int h = r1 - r0, w = c1 - c0;
+      const int cnt = sj == si ? h * (h + 1) / 2 : h * w;
+      if (rem < cnt) {
+        if (sj == si) {                       // diagonal super-tile: its own little upper triangle
+          int i = 0;
+          while (rem >= h - i) { rem -= h - i; ++i; }
+          bi = r0 + i;
+          bj = r0 + i + rem;
+        } else {
+          bi = r0 + rem / w;
+          bj = c0 + rem % w;
+        }
+        return;
+      }
+      rem -= cnt;
+    }
+  }
+  bi = bj = 0;                                // not reached for rem < nbk (nbk + 1) / 2
+}
 static constexpr int GK = 32;   // feature columns per LDS stage
 static constexpr int GLD = GK + 4;
 
@@ -88,9 +120,8 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
       rem = r % nblk;
     }
   }
-  int bi = 0;                                        // upper-triangular block index -> (bi, bj), bj >= bi
-  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
-  const int bj = bi + rem;
+  int bi, bj;                                        // upper-triangular block index -> (bi, bj), bj >= bi
+  gram_block_of(rem, nbk, bi, bj);
   const int I0 = bi * GB, J0 = bj * GB;
   const float* F = feats + (long)img * N * D;
   float* Wb = W + img * w_stride;
@@ -228,9 +259,8 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
       rem = r % nblk;
     }
   }
-  int bi = 0;
-  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
-  const int bj = bi + rem;
+  int bi, bj;
+  gram_block_of(rem, nbk, bi, bj);
   const int I0 = bi * GB, J0 = bj * GB;
   const f16* Hb = Hi + (long)img * N * D;
   const f16* Lb = Lo + (long)img * N * D;
@@ -360,9 +390,8 @@ __global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __r
       rem = r % nblk;
     }
   }
-  int bi = 0;
-  while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
-  const int bj = bi + rem;
+  int bi, bj;
+  gram_block_of(rem, nbk, bi, bj);
   const int I0 = bi * GB, J0 = bj * GB;
   const float* F = feats + (long)img * N * D;
   uint16_t* Wb = W + img * w_stride;
