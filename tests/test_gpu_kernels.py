@@ -512,3 +512,24 @@ def test_starved_image_falls_back_per_image_without_aborting_the_batch(capsys, m
         g = np.load(HERE / "golden" / f"eigs_{name}.npz")
         check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), g["eigenvectors"], g["eigenvalues"], what=name,
                    ext=golden_ext(g))
+
+
+# ----------------------------------------------------------------------------- the reference-side binding of INTEGRATION.md
+def test_integration_md_binding_stub_runs_against_the_library():
+    """INTEGRATION.md section B shows the ctypes stub a maintainer of the reference would add (`extract/dss_binding.py`).
+    Execute exactly that text against the in-tree library and hold its output to the reference's own golden."""
+    import re
+    from pathlib import Path
+    from tests.util import check_eigs, golden_case, golden_ext, build_w64
+
+    repo = Path(__file__).resolve().parents[1]
+    text = (repo / "INTEGRATION.md").read_text()
+    block = re.search(r"```python\n(# extract/dss_binding\.py.*?)```", text, re.S).group(1)
+    assert 'ctypes.CDLL("libdss_hip.so")' in block
+    block = block.replace('ctypes.CDLL("libdss_hip.so")', f'ctypes.CDLL("{hip.LIB_PATH}")')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md#dss_binding", "exec"), ns)
+    feats, K, lam, vec, g = golden_case(repo / "tests" / "golden" / "eigs_g2_blobs_900.npz")
+    val, v = ns["laplacian_eigs"](torch.from_numpy(feats).to(DEV), K)
+    assert val.device.type == "cpu" and tuple(v.shape) == (K, feats.shape[0])
+    check_eigs(v.numpy(), val.numpy(), vec, lam, what="INTEGRATION.md stub", d=build_w64(feats)[1], ext=golden_ext(g))

@@ -267,3 +267,17 @@ def test_file_io_worker_processes_round_trip(tmp_path):
     bad.submit_batch("features", (k.clone(),), [(0, 0, "x.jpg", "m", 16, (1, 3, 4, 4), str(tmp_path / "no_dir" / "x.pth"))])
     with pytest.raises(RuntimeError):
         bad.close()
+
+
+def test_integration_md_binding_stub_matches_the_declared_abi():
+    """Every `_lib.<symbol>.argtypes = [...]` line of INTEGRATION.md's reference-side stub names an exported symbol with
+    the right number of arguments (the GPU suite executes the stub; this keeps the document honest without one)."""
+    text = (REPO / "INTEGRATION.md").read_text()
+    block = re.search(r"```python\n(# extract/dss_binding\.py.*?)```", text, re.S).group(1)
+    found = re.findall(r"_lib\.(dss_[a-z0-9_]+)\.argtypes = \[([^\]]*)\]", block)
+    assert len(found) >= 5
+    for name, args in found:
+        assert name in hip.SYMBOLS, name
+        assert len([a for a in args.split(",") if a.strip()]) == len(hip.SYMBOLS[name][1]), name
+    for name in re.findall(r"_lib\.(dss_[a-z0-9_]+)\(", block):
+        assert name in hip.SYMBOLS, name
