@@ -191,11 +191,22 @@ def _np_knn_affinity(image, n_neighbors=(20, 10), distance_weights=(2.0, 0.1)):
     return np.asarray(scipy.sparse.csr_matrix((np.ones(2 * sum(n_neighbors) * n), (ij, ji)), (n, n)).todense())
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("hw", [(14, 14), (18, 22), (30, 30)])
-def test_knn_affinity_on_gpu_matches_kdtree(hw):
+def _device(name):
+    if name == "cuda" and not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device(name)
+
+
+@pytest.mark.parametrize("hw,dev", [((14, 14), "cpu"), ((18, 22), "cpu"),
+                                    pytest.param((14, 14), "cuda", marks=pytest.mark.gpu),
+                                    pytest.param((18, 22), "cuda", marks=pytest.mark.gpu),
+                                    pytest.param((30, 30), "cuda", marks=pytest.mark.gpu)])
+def test_knn_affinity_matches_kdtree(hw, dev):
+    """The colour-affinity builder is plain device-agnostic tensor code: the same check on the host (every round's CPU
+    suite) and on the GPU."""
+    dev = _device(dev)
     img = synthetic.synthetic_image(31, hw[0], hw[1]).astype(np.float64) / 255.0
-    got = extract_utils.knn_affinity(torch.from_numpy(img).cuda()).cpu().numpy()
+    got = extract_utils.knn_affinity(torch.from_numpy(img).to(dev)).cpu().numpy()
     want = _np_knn_affinity(img)
     assert got.shape == want.shape and np.array_equal(got, got.T)
     # identical to the kd-tree's graph except in rows where the k-th and (k+1)-th neighbour are at EXACTLY the same
@@ -212,12 +223,13 @@ def test_knn_affinity_on_gpu_matches_kdtree(hw):
     assert len(bad) <= 4 * tied.sum()
     assert np.all(np.diag(got) == 4) and got.sum() == 2 * 30 * hw[0] * hw[1]
     with pytest.raises(ValueError):
-        extract_utils.knn_affinity(torch.zeros(3, 3, 3).cuda())      # 9 pixels, 20 neighbours asked
+        extract_utils.knn_affinity(torch.zeros(3, 3, 3, device=dev))      # 9 pixels, 20 neighbours asked
 
 
-@pytest.mark.gpu
-def test_rw_affinity_on_gpu_matches_pixel_loop():
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_rw_affinity_matches_pixel_loop(dev):
     """Scalar restatement of the documented random-walk weights (window r = 1, clamped coordinates, duplicates add)."""
+    dev = _device(dev)
     img = synthetic.synthetic_image(32, 9, 7).astype(np.float64) / 255.0
     h, w = img.shape[:2]
     want = np.zeros((h * w, h * w))
@@ -227,7 +239,7 @@ def test_rw_affinity_on_gpu_matches_pixel_loop():
                 for dx in (-1, 0, 1):
                     y2, x2 = max(0, min(h - 1, y + dy)), max(0, min(w - 1, x + dx))
                     want[x + y * w, x2 + y2 * w] += np.exp(-np.sum((img[y, x] - img[y2, x2]) ** 2) / 0.033 ** 2)
-    got = extract_utils.rw_affinity(torch.from_numpy(img).cuda()).cpu().numpy()
+    got = extract_utils.rw_affinity(torch.from_numpy(img).to(dev)).cpu().numpy()
     assert np.allclose(got, want, rtol=1e-6, atol=1e-9) and np.allclose(got, got.T)
 
 
