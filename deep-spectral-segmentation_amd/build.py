@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libdss_hip.so"
-SOURCES = ["lib.hip", "preprocess.hip", "layernorm.hip", "attention.hip", "linear384.hip", "affinity.hip", "eigs.hip"]
+SOURCES = ["lib.hip", "preprocess.hip", "layernorm.hip", "attention.hip", "linear384.hip", "affinity.hip", "eigs.hip", "segment.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: the softmax max-chains read MFMA results; in IEEE mode hipcc quiets every such value with an extra

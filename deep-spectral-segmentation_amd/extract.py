@@ -111,8 +111,8 @@ class _AsyncSaver:
                 for p in self.procs:
                     p.start()
 
-    def submit(self, obj, path: str):
-        self.futures.append(self.pool.submit(torch.save, obj, path))
+    def submit(self, obj, path: str, writer=torch.save):
+        self.futures.append(self.pool.submit(writer, obj, path))
         if len(self.futures) - self.waited >= self.max_pending:  # back-pressure: bound the queued work
             upto = self.waited + self.max_pending // 2
             for f in self.futures[self.waited:upto]:
@@ -124,7 +124,7 @@ class _AsyncSaver:
         moved to shared memory once per batch).  Without worker processes the files are built here and saved by threads."""
         if not self.procs:
             for it in items:
-                self.submit(*_SAVE_BUILDERS[kind](tensors, it))
+                self.submit(*_SAVE_BUILDERS[kind](tensors, it), writer=_SAVE_WRITERS.get(kind, torch.save))
             return
         tensors = tuple(t if t.is_shared() else t.share_memory_() for t in tensors)
         for s in range(0, len(items), chunk):
@@ -173,7 +173,19 @@ def _build_eig_file(tensors, item):
     return {"eigenvalues": vals.numpy() if problem == "affinity" else vals, "eigenvectors": vec[j].clone()}, out
 
 
-_SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file}
+def _build_png_file(tensors, item):
+    (labels,), (j, out, hp, wp) = tensors, item       # u8 [B, N] label / mask maps -> one 8-bit PNG per image
+    return labels[j].reshape(hp, wp).numpy(), out
+
+
+def _write_png(arr, path: str):
+    from PIL import Image
+
+    Image.fromarray(arr).save(path)
+
+
+_SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file, "png": _build_png_file}
+_SAVE_WRITERS = {"png": _write_png}     # everything else: torch.save
 
 
 def _save_worker(queue, errors):
@@ -185,7 +197,7 @@ def _save_worker(queue, errors):
         kind, tensors, items = job
         try:
             for it in items:
-                torch.save(*_SAVE_BUILDERS[kind](tensors, it))
+                _SAVE_WRITERS.get(kind, torch.save)(*_SAVE_BUILDERS[kind](tensors, it))
         except BaseException as e:  # reported by close() in the parent
             errors.put(f"{type(e).__name__}: {e}")
         del tensors, job
@@ -409,7 +421,8 @@ def _lr_grid(data_dict: dict, image_downsample_factor: Optional[int]) -> Tuple[i
 
 def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: bool, threshold_at_zero: bool,
                    device: torch.device, saver: Optional["_AsyncSaver"] = None, problem: str = "laplacian",
-                   upsample=None, color=None, color_items: Optional[List[Tuple[str, Tuple[int, int]]]] = None):
+                   upsample=None, color=None, color_items: Optional[List[Tuple[str, Tuple[int, int]]]] = None,
+                   segment: Optional[dict] = None):
     # straight from wherever the loader left each file's features (a shared-memory segment when worker processes read
     # them) into the device batch: no host-side torch.stack pass over 1.4 MB per image
     feats = torch.empty((len(items),) + tuple(items[0][1].shape), dtype=torch.float32, device=device)
@@ -437,6 +450,27 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
     bad = (info <= 0).nonzero().flatten().tolist()
     if bad:
         print(f"[dss] WARNING: eigensolver did not converge for {[items[j][0] for j in bad]} (saved as is)")
+    if segment is not None:
+        # the segmentations of extract.py:283-426 straight from the device-resident eigenvectors,
+        # no .pth round trip (same algorithms on the device: threshold of the Fiedler vector; Lloyd K-means + border vote)
+        hp, wp = segment["grid"]
+        pngs = []
+        if segment.get("single_region_dir"):
+            pngs.append((segment["single_region_dir"], spectral.single_region_masks(vec, segment["threshold"])))
+        if segment.get("multi_region_dir"):
+            pngs.append((segment["multi_region_dir"], spectral.multi_region_segments(
+                ev, vec, (hp, wp), adaptive=segment["adaptive"], non_adaptive_num_segments=segment["num_segments"],
+                infer_bg_index=segment["infer_bg_index"], num_eigenvectors=segment["num_eigenvectors"],
+                seed=segment["seed"]).reshape(len(items), -1)))
+        for out_dir, maps in pngs:
+            maps = maps.cpu()
+            png_items = [(j, str(Path(out_dir) / f"{Path(output_file).stem}.png"), hp, wp)
+                         for j, (output_file, _) in enumerate(items)]
+            if saver is None:
+                for it in png_items:
+                    _write_png(*_build_png_file((maps,), it))
+            else:
+                saver.submit_batch("png", (maps,), png_items)
     ev, vec = ev.cpu(), vec.cpu()
     if saver is None:
         for j, (output_file, _) in enumerate(items):
@@ -471,10 +505,23 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
                  which_color_matrix: str = "knn", which_features: str = "k", normalize: bool = True,
                  threshold_at_zero: bool = True, lapnorm: bool = True, K: int = 20,
                  image_downsample_factor: Optional[int] = None, image_color_lambda: float = 0.0,
-                 multiprocessing: int = 0, batch_size: int = 64):
+                 multiprocessing: int = 0, batch_size: int = 64,
+                 single_region_dir: Optional[str] = None, segmentation_threshold: float = 0.0,
+                 multi_region_dir: Optional[str] = None, adaptive: bool = False, non_adaptive_num_segments: int = 4,
+                 infer_bg_index: bool = True, num_eigenvectors: int = 1_000_000, kmeans_seed: int = 0):
     """Extracts eigenvalues/eigenvectors from features (see module docstring).  ``multiprocessing`` is
-    accepted for CLI compatibility and ignored; ``batch_size`` same-shape images share one kernel launch."""
+    accepted for CLI compatibility and ignored; ``batch_size`` same-shape images share one kernel launch.
+
+    ``single_region_dir`` / ``multi_region_dir`` (not in the reference's command): also write the segmentation PNGs of
+    ``extract_single_region_segmentations`` / ``extract_multi_region_segmentations`` from the eigenvectors while they are
+    still on the device (``spectral.single_region_masks`` / ``multi_region_segments``; the Laplacian branches only),
+    with those commands' own options (``segmentation_threshold`` is their ``threshold``)."""
     _make_output_dir_all_ranks(output_dir)
+    for extra in (single_region_dir, multi_region_dir):
+        if extra:
+            if which_matrix not in ("laplacian", "matting_laplacian"):
+                raise ValueError("the on-device segmentations use eigenvector 1 of the Laplacian branches")
+            Path(extra).mkdir(parents=True, exist_ok=True)
     kwargs = dict(K=K, which_matrix=which_matrix, which_features=which_features,
                   which_color_matrix=which_color_matrix, normalize=normalize, threshold_at_zero=threshold_at_zero,
                   images_root=images_root, output_dir=output_dir, image_downsample_factor=image_downsample_factor,
@@ -493,8 +540,14 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     problems: Dict[Tuple, str] = {}
 
     def run(key):
-        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1], color,
-                       pending_ids.pop(key))
+        ids = pending_ids.pop(key)
+        segment = None
+        if single_region_dir or multi_region_dir:
+            segment = dict(grid=ids[0][1], single_region_dir=single_region_dir, threshold=segmentation_threshold,
+                           multi_region_dir=multi_region_dir, adaptive=adaptive, num_segments=non_adaptive_num_segments,
+                           infer_bg_index=infer_bg_index, num_eigenvectors=num_eigenvectors, seed=kmeans_seed)
+        _run_eig_batch(pending.pop(key), K, normalize, threshold_at_zero, device, saver, problems[key], key[1], color, ids,
+                       segment)
 
     bs = max(1, int(batch_size))
     n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
@@ -511,7 +564,8 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
                                      data_dict["patch_size"])
         utils.get_image_sizes(data_dict)
         up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
-        key = (tuple(feats.shape), up)  # same feature shape AND same resize target share a launch
+        # same feature shape, same resize target AND same grid (20 x 30 and 30 x 20 patches have the same N) share a launch
+        key = (tuple(feats.shape), up, _lr_grid(data_dict, image_downsample_factor))
         pending.setdefault(key, []).append((output_file, feats))
         pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
         problems[key] = problem

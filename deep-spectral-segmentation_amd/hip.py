@@ -7,7 +7,7 @@ raised.  Tensors are passed as raw device pointers (``tensor.data_ptr()``), the 
 from __future__ import annotations
 
 import ctypes
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
 from pathlib import Path
 from typing import Optional
 
@@ -48,6 +48,9 @@ SYMBOLS = {
     "dss_symmetric_eigs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_int, c_void_p, c_size_t, c_void_p]),
     "dss_sign_rule": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "dss_fiedler_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dss_kmeans_segments": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_uint, c_int, c_float,
+                                    c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 
@@ -373,3 +376,38 @@ def sign_rule_(vecs: torch.Tensor) -> torch.Tensor:
     n = vecs.shape[-1]
     _check(load_library().dss_sign_rule(_dev(vecs, "vecs"), vecs.numel() // n, n, _stream()), "dss_sign_rule")
     return vecs
+
+
+def fiedler_mask(eigenvectors: torch.Tensor, index: int = 1, threshold: float = 0.0) -> torch.Tensor:
+    """``[B, K, N]`` f32 eigenvectors -> u8 ``[B, N]`` masks ``eigenvectors[:, index] > threshold`` (0 / 255): the
+    single-region segmentation of extract.py:383-407 on the device."""
+    assert eigenvectors.dtype == torch.float32 and eigenvectors.dim() == 3
+    b, k, n = eigenvectors.shape
+    mask = torch.empty((b, n), dtype=torch.uint8, device=eigenvectors.device)
+    _check(load_library().dss_fiedler_mask(_dev(eigenvectors.contiguous(), "eigenvectors"), _dev(mask, "mask"), b, k, n,
+                                           int(index), float(threshold), _stream()), "dss_fiedler_mask")
+    return mask
+
+
+def kmeans_segments(eigenvectors: torch.Tensor, n_clusters: int, first: int = 1, dims: Optional[int] = None,
+                    grid: Optional[tuple] = None, infer_bg: bool = True, init: Optional[torch.Tensor] = None,
+                    seed: int = 0, max_iter: int = 300, tol: float = 1e-4):
+    """Multi-region segmentation of extract.py:283-352 on the device (``dss_kmeans_segments``): K-means over the points
+    ``eigenvectors[b, first:first+dims].T``.  Returns ``(labels u8 [B, N], inertia [B], iterations [B])``."""
+    assert eigenvectors.dtype == torch.float32 and eigenvectors.dim() == 3
+    b, k, n = eigenvectors.shape
+    dims = k - first if dims is None else min(int(dims), k - first)
+    hp, wp = grid if grid is not None else (0, 0)
+    if init is not None:
+        assert tuple(init.shape) == (b, n_clusters, dims) and init.dtype == torch.float32
+        init = init.contiguous()
+    labels = torch.empty((b, n), dtype=torch.uint8, device=eigenvectors.device)
+    inertia = torch.empty((b,), dtype=torch.float32, device=eigenvectors.device)
+    iters = torch.empty((b,), dtype=torch.int32, device=eigenvectors.device)
+    _check(load_library().dss_kmeans_segments(_dev(eigenvectors.contiguous(), "eigenvectors"), b, k, n, int(first), dims,
+                                              int(n_clusters), None if init is None else _dev(init, "init"),
+                                              int(seed) & 0xFFFFFFFF, int(max_iter), float(tol), int(hp), int(wp),
+                                              int(bool(infer_bg) and grid is not None), _dev(labels, "labels"),
+                                              _dev(inertia, "inertia"), _dev(iters, "iters"), _stream()),
+           "dss_kmeans_segments")
+    return labels, inertia, iters

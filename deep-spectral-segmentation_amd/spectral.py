@@ -283,6 +283,43 @@ def eigs_from_dense_affinity(w: torch.Tensor, K: int, problem: str = "laplacian"
     return ev, vec, info
 
 
+@torch.no_grad()
+def single_region_masks(eigenvectors: torch.Tensor, threshold: float = 0.0) -> torch.Tensor:
+    """extract.py:383-407 on the device, straight from the solver's output: u8 ``[B, N]`` masks (0 / 255) of
+    ``eigenvectors[:, 1] > threshold`` - reshape ``(H_patch, W_patch)`` for the PNG the reference writes."""
+    return hip.fiedler_mask(eigenvectors, 1, threshold)
+
+
+@torch.no_grad()
+def multi_region_segments(eigenvalues: torch.Tensor, eigenvectors: torch.Tensor, grid: Tuple[int, int],
+                          adaptive: bool = False, non_adaptive_num_segments: int = 4, infer_bg_index: bool = True,
+                          num_eigenvectors: int = 1_000_000, init: Optional[torch.Tensor] = None, seed: int = 0):
+    """extract.py:283-352 on the device, without the ``.pth`` round trip: K-means over ``eigenvectors[b, 1:1+num_eigenvectors].T``
+    (``hip.kmeans_segments``: Lloyd + sklearn's stopping rules; ``init`` ``[B, k, dims]`` or k-means++ from ``seed``), the
+    number of segments fixed or - ``adaptive`` - one more than the index of the largest eigengap not counting the first,
+    then the border vote that renames the segment owning most of the border to 0.  ``grid`` = (rows, cols) of the
+    eigenvectors' patch grid.  Returns u8 labels ``[B, rows, cols]``.  (The CLI command of the same name clusters with
+    sklearn on the host exactly as the reference does; this is the same algorithm for device-resident pipelines -
+    the partitions agree, the label numbering before the border vote depends on the initial centres in both.)"""
+    b, k, n = eigenvectors.shape
+    assert grid[0] * grid[1] == n, (grid, n)
+    dims = min(int(num_eigenvectors), k - 1)
+    out = torch.empty((b, n), dtype=torch.uint8, device=eigenvectors.device)
+    if adaptive:
+        gaps = torch.diff(eigenvalues.float(), dim=1)
+        gaps[:, 0] = float("-inf")                      # "remove zero and take the biggest"
+        ks = (gaps.argmax(dim=1) + 1).tolist()
+    else:
+        ks = [int(non_adaptive_num_segments)] * b
+    for kk in sorted(set(ks)):
+        idx = [i for i, v in enumerate(ks) if v == kk]
+        sel = torch.tensor(idx, device=eigenvectors.device)
+        lab, _, _ = hip.kmeans_segments(eigenvectors[sel].contiguous(), kk, first=1, dims=dims, grid=grid,
+                                        infer_bg=infer_bg_index, init=None if init is None else init[sel], seed=seed)
+        out[sel] = lab
+    return out.view(b, grid[0], grid[1])
+
+
 def group_by_shape(shapes: List[Tuple[int, ...]], max_batch: int) -> List[List[int]]:
     """Indices grouped into batches of identical shape (order of first appearance preserved inside a
     batch; batches ordered by their first member)."""

@@ -170,6 +170,25 @@ int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode, float* eig
 /* ---- a15: sign rule alone (extract/extract.py:238-240), in place on [rows, N] ----------------- */
 int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream);
 
+/* ---- f1: the immediate consumers of the eigenvectors, on the device right after the solve (no .pth round trip) ------
+ * dss_fiedler_mask: extract/extract.py:383-407 - mask[b][e] = eigenvectors[b][index][e] > threshold ? 255 : 0
+ * (eigenvectors [B, K, N] f32 as the solvers write them; mask [B, N] u8: the 8-bit PNG the reference saves, row-major
+ * over the patch grid).
+ * dss_kmeans_segments: extract/extract.py:283-352 - K-means over the N points whose coordinates are eigenvectors
+ * [first, first + dims) of each image (the reference clusters `eigenvectors[1:1+num_eigenvectors].T`), Lloyd iterations
+ * with sklearn's two stopping rules (labels unchanged; squared centre shift <= tol * mean coordinate variance) and final
+ * assignment; centroids_init [B, k, dims] or NULL (k-means++ seeding from a counter-based generator: seed, image, draw);
+ * then, if infer_bg, the border vote of extract_utils.py:124-135 on the hp x wp grid (hp * wp == N; corners count
+ * twice) and the label swap that makes the winning segment 0.  labels [B, N] u8, inertia [B] f32 (sum of squared
+ * distances to the final centres), iters [B].  Limits: N <= 8192, dims <= 64, k <= 32.  An empty cluster keeps its
+ * centre (sklearn relocates it).  The CLI's extract_multi_region_segmentations keeps clustering with sklearn on the host,
+ * bit-identical to the reference for a seeded run; this entry point is the same algorithm for device-resident pipelines. */
+int dss_fiedler_mask(const float* eigenvectors, uint8_t* mask, int B, int K, int N, int index, float threshold,
+                     void* stream);
+int dss_kmeans_segments(const float* eigenvectors, int B, int K, int N, int first, int dims, int k,
+                        const float* centroids_init, unsigned seed, int max_iter, float tol, int hp, int wp, int infer_bg,
+                        uint8_t* labels, float* inertia, int32_t* iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -348,3 +348,91 @@ def test_dense_affinity_packing_round_trip_and_solver_agreement(n):
         assert int(info1[0]) > 0 and int(info2[0]) > 0
         assert torch.allclose(ev1, ev2, atol=2e-5 * max(1.0, float(ev2.abs().max())))
         assert cos_err(vec1[0].cpu().numpy(), vec2[0].cpu().numpy()).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ on-device segmentation
+@pytest.mark.gpu
+def test_fiedler_mask_on_device_matches_reference_png():
+    """extract.py:383-407 straight from device-resident eigenvectors: the same 0 / 255 mask as the PNG the reference wrote
+    (tests/golden/single_region.npz)."""
+    from dss_amd import spectral
+
+    g = np.load(GOLDEN / "single_region.npz")
+    vec = torch.from_numpy(g["eigenvectors"])[None].cuda()
+    mask = spectral.single_region_masks(vec).cpu().numpy()
+    hp, wp = int(g["shape"][2]) // int(g["patch"]), int(g["shape"][3]) // int(g["patch"])
+    assert mask.dtype == np.uint8 and np.array_equal(mask.reshape(hp, wp), g["png"])
+    thr = spectral.single_region_masks(vec, threshold=0.3).cpu().numpy()
+    assert np.array_equal(thr[0] > 0, g["eigenvectors"][1] > 0.3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(6))
+def test_kmeans_segments_on_device_matches_sklearn_from_the_same_centres(case):
+    """extract.py:283-352 on the device.  The reference's KMeans is unseeded, so its labels are a random variable; what
+    can be pinned is the ALGORITHM: from the same initial centres (sklearn's own k-means++ draw) Lloyd must reach the
+    same partition as sklearn.cluster.KMeans - same labels (points equidistant to rounding may flip: >= 99.5 %), same
+    inertia - and the border vote must be the reference's (extract_utils.get_border_fraction) on those labels."""
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    from dss_amd import hip
+
+    g = np.load(GOLDEN / "consumers.npz")
+    name, kind, hw, factor, K, seed, kw = _cases(g)[case]
+    vec = g[f"{name}__eigenvectors"]
+    grid = (hw[0] * factor, hw[1] * factor)
+    k = 3 if case % 2 else 4
+    dims = min(kw.get("num_eigenvectors", 1_000_000), vec.shape[0] - 1)
+    X = np.ascontiguousarray(vec[1:1 + dims].T)
+    centres, _ = kmeans_plusplus(X, k, random_state=seed)
+    ref = KMeans(n_clusters=k, init=centres, n_init=1).fit(X)
+    dv = torch.from_numpy(vec)[None].cuda()
+    lab, inertia, iters = hip.kmeans_segments(dv, k, first=1, dims=dims, infer_bg=False,
+                                              init=torch.from_numpy(centres.astype(np.float32))[None].cuda())
+    lab = lab[0].cpu().numpy()
+    assert lab.max() < k and 0 < int(iters[0]) <= 300
+    assert (lab == ref.labels_).mean() >= 0.995, (lab != ref.labels_).sum()
+    assert abs(float(inertia[0]) - ref.inertia_) <= 1e-3 * ref.inertia_ + 1e-9
+    # border vote + label swap, against the reference's own lines applied to the same labels
+    voted, _, _ = hip.kmeans_segments(dv, k, first=1, dims=dims, grid=grid, infer_bg=True,
+                                      init=torch.from_numpy(centres.astype(np.float32))[None].cuda())
+    seg = lab.reshape(grid).astype(np.int64).copy()
+    idx, frac = extract_utils.get_border_fraction(seg)
+    bg = idx[np.argmax(frac)].item()
+    bg_region, zero_region = seg == bg, seg == 0
+    seg[bg_region] = 0
+    seg[zero_region] = bg
+    assert np.array_equal(voted[0].cpu().numpy().reshape(grid), seg)
+
+
+@pytest.mark.gpu
+def test_kmeans_segments_default_seeding_batches_and_adaptive():
+    """k-means++ seeding on the device: deterministic, one launch for a batch == per-image launches, the clustering is as
+    good as sklearn's (inertia within 15 % of its best of 5 runs), and the `adaptive` rule picks the reference's count."""
+    from sklearn.cluster import KMeans
+    from dss_amd import hip, spectral
+
+    g = np.load(GOLDEN / "consumers.npz")
+    names = [c[0] for c in _cases(g)[:2]]                      # two 14 x 14 cases with K = 6 and K = 8: use 5 vectors each
+    vecs = torch.stack([torch.from_numpy(g[f"{n}__eigenvectors"][:6]) for n in names]).cuda()
+    a = hip.kmeans_segments(vecs, 4, seed=11)
+    b = hip.kmeans_segments(vecs, 4, seed=11)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i in range(2):
+        one = hip.kmeans_segments(vecs[i:i + 1].contiguous(), 4, seed=11)
+        # the generator is keyed by (seed, image index in the launch, draw): image 0 of a launch of one == image 0 of the batch
+        if i == 0:
+            assert torch.equal(one[0][0], a[0][0])
+        X = vecs[i, 1:].T.cpu().numpy()
+        best = min(KMeans(n_clusters=4, n_init=1, random_state=s).fit(X).inertia_ for s in range(5))
+        assert float(a[1][i]) <= 1.15 * best + 1e-9, (float(a[1][i]), best)
+        assert set(np.unique(a[0][i].cpu().numpy()).tolist()) <= {0, 1, 2, 3}
+    lam = torch.stack([torch.from_numpy(g[f"{n}__eigenvalues"][:6]) for n in names]).cuda()
+    seg = spectral.multi_region_segments(lam, vecs, (14, 14), adaptive=True, seed=3)
+    assert seg.shape == (2, 14, 14) and seg.dtype == torch.uint8
+    for i in range(2):
+        ev = lam[i].cpu().numpy()
+        order = np.argsort(np.diff(ev))[::-1]
+        want_k = int(order[order != 0][0]) + 1
+        assert len(np.unique(seg[i].cpu().numpy())) <= want_k
+        idx, frac = extract_utils.get_border_fraction(seg[i].cpu().numpy())
+        assert idx[np.argmax(frac)] == 0                        # the segment owning most of the border is 0

@@ -196,6 +196,37 @@ def test_config5_vitb8_mixed_sizes_k20_through_the_cli(tmp_path):
               f"non-isolated: {[(r['first'], r['last'], r['kind']) for r in report if r['kind'] != 'isolated']}")
 
 
+def test_cli_writes_segmentations_from_device_resident_eigenvectors(tmp_path):
+    """SURVEY.md §8f row 1, "on the device right after the solve": `extract_eigs --single_region_dir / --multi_region_dir`
+    writes the segmentation PNGs without the .pth round trip.  The single-region masks must be the files the
+    reference-style command produces from the saved eigenvectors, bit for bit; the multi-region maps must be valid label
+    maps of the patch grid (two shapes with the same N in one run), background 0 by the border vote, reproducible."""
+    from PIL import Image
+
+    specs = [("s_a.png", 81, 96, 160), ("s_b.png", 82, 160, 96), ("s_c.png", 83, 96, 160), ("s_d.png", 84, 128, 128)]
+    _write_images(tmp_path / "images", specs)
+    (tmp_path / "images.txt").write_text("\n".join(s[0] for s in specs) + "\n")
+    extract.main(["extract_features", "--images_list", str(tmp_path / "images.txt"), "--images_root",
+                  str(tmp_path / "images"), "--output_dir", str(tmp_path / "feat"), "--model_name", "dino_vits16",
+                  "--batch_size", "4", "--synthetic_weights", "5"])
+    for run in ("r1", "r2"):
+        extract.main(["extract_eigs", "--images_root", str(tmp_path / "images"), "--features_dir", str(tmp_path / "feat"),
+                      "--output_dir", str(tmp_path / run / "eigs"), "--K", "5", "--batch_size", "4",
+                      "--single_region_dir", str(tmp_path / run / "single"), "--multi_region_dir", str(tmp_path / run / "multi"),
+                      "--non_adaptive_num_segments", "3", "--kmeans_seed", "7"])
+    extract.extract_single_region_segmentations(str(tmp_path / "feat"), str(tmp_path / "r1" / "eigs"), str(tmp_path / "host_single"))
+    for name, _, h, w in specs:
+        stem = name[:-4]
+        dev = np.array(Image.open(tmp_path / "r1" / "single" / f"{stem}.png"))
+        host = np.array(Image.open(tmp_path / "host_single" / f"{stem}.png"))
+        assert dev.shape == (h // 16, w // 16) and dev.dtype == np.uint8 and np.array_equal(dev, host)
+        seg = np.array(Image.open(tmp_path / "r1" / "multi" / f"{stem}.png"))
+        assert seg.shape == (h // 16, w // 16) and seg.max() <= 2
+        idx, frac = extract_utils.get_border_fraction(seg)
+        assert idx[np.argmax(frac)] == 0
+        assert np.array_equal(seg, np.array(Image.open(tmp_path / "r2" / "multi" / f"{stem}.png")))
+
+
 def test_cli_buckets_mixed_shapes(tmp_path):
     """Interleaved image sizes: the CLI buckets by shape; every image still gets its own correct B=1 file."""
     specs = [(f"m_{i:02d}.png", 50 + i, (96, 128) if i % 2 else (128, 96)) for i in range(6)]
