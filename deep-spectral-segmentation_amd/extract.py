@@ -21,7 +21,8 @@ feature upsampling (``image_downsample_factor``) and the colour-affinity fusion 
 
 The consumers of the eigen files keep the reference's names and file formats too:
 ``extract_single_region_segmentations`` (:383-426), ``extract_multi_region_segmentations`` (:283-377),
-``extract_bboxes`` (:429-495) and ``extract_bbox_features`` (:498-544).
+``extract_bboxes`` (:429-495), ``extract_bbox_features`` (:498-544), ``extract_bbox_clusters`` (:547-599) and
+``extract_semantic_segmentations`` (:602-647).
 """
 from __future__ import annotations
 
@@ -737,11 +738,74 @@ def extract_bbox_features(images_root: str, bbox_file: str, model_name: str, out
     print(f"Saved features to {output_file}")
 
 
+def extract_bbox_clusters(bbox_features_file: str, output_file: str, num_clusters: int = 20, seed: int = 0,
+                          pca_dim: Optional[int] = 0):
+    """python extract.py extract_bbox_clusters --bbox_features_file F --pca_dim 32 --num_clusters 21 --seed 0
+    --output_file O   (reference extract/extract.py:547-599): L2-normalise the box features of the whole dataset, optional
+    PCA, MiniBatchKMeans - sklearn with the reference's own parameters, so a given ``seed`` reproduces its clusters -
+    and write the list back with ``'clusters'`` in place of ``'features'``.  Host side: a few thousand boxes."""
+    import numpy as np
+    from sklearn.cluster import MiniBatchKMeans
+    from sklearn.decomposition import PCA
+
+    bbox_list = torch.load(bbox_features_file, weights_only=False)
+    total_num_boxes = sum(len(d["bboxes"]) for d in bbox_list)
+    print(f"Loaded bounding box list. There are {total_num_boxes} total bounding boxes with features.")
+    all_features = torch.cat([d["features"] for d in bbox_list], dim=0)
+    all_features = (all_features / torch.norm(all_features, dim=-1, keepdim=True)).numpy()
+    if pca_dim:
+        print(f"Computing PCA with dimension {pca_dim}")
+        all_features = PCA(pca_dim).fit_transform(all_features)
+    print(f"Computing K-Means clustering with {num_clusters} clusters")
+    kmeans = MiniBatchKMeans(n_clusters=num_clusters, batch_size=4096, max_iter=5000, random_state=seed)
+    clusters = kmeans.fit_predict(all_features)
+    _indices, _counts = np.unique(clusters, return_counts=True)
+    print(f"Cluster indices: {_indices.tolist()}")
+    print(f"Cluster counts: {_counts.tolist()}")
+    idx = 0
+    for bbox_dict in bbox_list:
+        num_bboxes = len(bbox_dict["bboxes"])
+        del bbox_dict["features"]
+        bbox_dict["clusters"] = clusters[idx: idx + num_bboxes]
+        idx += num_bboxes
+    torch.save(bbox_list, output_file)
+    print(f"Saved features to {output_file}")
+
+
+def extract_semantic_segmentations(segmentations_dir: str, bbox_clusters_file: str, output_dir: str):
+    """python extract.py extract_semantic_segmentations --segmentations_dir S --bbox_clusters_file C --output_dir O
+    (reference extract/extract.py:602-647): every segment of a multi-region map takes the cluster id of its box; segment 0
+    (background) stays 0; a 0 / 255 binary map counts as 0 / 1."""
+    import numpy as np
+    from PIL import Image
+
+    bbox_list = torch.load(bbox_clusters_file, weights_only=False)
+    total_num_boxes = sum(len(d["bboxes"]) for d in bbox_list)
+    print(f"Loaded bounding box list. There are {total_num_boxes} total bounding boxes with features and clusters.")
+    utils.make_output_dir(output_dir)
+    for bbox_dict in bbox_list:
+        image_id = bbox_dict["id"]
+        segmap = np.array(Image.open(str(Path(segmentations_dir) / f"{image_id}.png")))
+        if set(np.unique(segmap).tolist()).issubset({0, 255}):
+            segmap[segmap == 255] = 1
+        clusters = np.asarray(bbox_dict["clusters"]).tolist()
+        if len(bbox_dict["segment_indices"]) != len(clusters):   # the reference drops into pdb here
+            raise ValueError(f"{image_id}: {len(bbox_dict['segment_indices'])} segments but {len(clusters)} clusters")
+        semantic_map = dict(zip(bbox_dict["segment_indices"], clusters))
+        assert 0 not in semantic_map, semantic_map
+        semantic_map[0] = 0
+        semantic_segmap = np.vectorize(semantic_map.__getitem__)(segmap)
+        Image.fromarray(semantic_segmap.astype(np.uint8)).convert("L").save(str(Path(output_dir) / f"{image_id}.png"))
+    print(f"Saved features to {output_dir}")
+
+
 # ------------------------------------------------------------------------------------------ CLI
 COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs,
                 extract_single_region_segmentations=extract_single_region_segmentations,
                 extract_multi_region_segmentations=extract_multi_region_segmentations,
-                extract_bboxes=extract_bboxes, extract_bbox_features=extract_bbox_features)
+                extract_bboxes=extract_bboxes, extract_bbox_features=extract_bbox_features,
+                extract_bbox_clusters=extract_bbox_clusters,
+                extract_semantic_segmentations=extract_semantic_segmentations)
 
 
 def _literal(s: str):

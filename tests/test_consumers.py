@@ -436,3 +436,37 @@ def test_kmeans_segments_default_seeding_batches_and_adaptive():
         assert len(np.unique(seg[i].cpu().numpy())) <= want_k
         idx, frac = extract_utils.get_border_fraction(seg[i].cpu().numpy())
         assert idx[np.argmax(frac)] == 0                        # the segment owning most of the border is 0
+
+
+@pytest.mark.parametrize("run", range(2))
+def test_bbox_clusters_and_semantic_segmentations_match_reference(tmp_path, run):
+    """extract/extract.py:547-647: PCA + seeded MiniBatchKMeans over the box features of the whole set, then every segment
+    takes its box's cluster id - same cluster arrays and same PNGs as the reference (tests/golden/semantic.npz)."""
+    from PIL import Image
+
+    g = np.load(GOLDEN / "semantic.npz")
+    c = np.load(GOLDEN / "consumers.npz")
+    tag, kw = json.loads(str(g["runs"]))[run]
+    boxes = json.loads(str(g["boxes"]))
+    (tmp_path / "s").mkdir()
+    bbox_list = []
+    for d in boxes:
+        Image.fromarray(c[f"{d['id']}__png"]).save(tmp_path / "s" / f"{d['id']}.png")
+        bbox_list.append(dict(d, features=torch.from_numpy(g[f"{d['id']}__features"])))
+    torch.save(bbox_list, tmp_path / "bf.pth")
+    extract.extract_bbox_clusters(bbox_features_file=str(tmp_path / "bf.pth"), output_file=str(tmp_path / "c.pth"), **kw)
+    res = torch.load(tmp_path / "c.pth", weights_only=False)
+    want = json.loads(str(g[f"clusters__{tag}"]))
+    assert [np.asarray(d["clusters"]).tolist() for d in res] == want
+    assert all("features" not in d and isinstance(d["clusters"], np.ndarray) for d in res)
+    assert str(np.asarray(res[0]["clusters"]).dtype) == str(g[f"clusters_dtype__{tag}"])
+    extract.extract_semantic_segmentations(segmentations_dir=str(tmp_path / "s"), bbox_clusters_file=str(tmp_path / "c.pth"),
+                                           output_dir=str(tmp_path / "sem"))
+    for d in res:
+        got = np.array(Image.open(tmp_path / "sem" / f"{d['id']}.png"))
+        assert got.dtype == np.uint8 and np.array_equal(got, g[f"semantic__{tag}__{d['id']}"]), d["id"]
+    # a binary 0 / 255 map counts as 0 / 1 (the reference's baselines)
+    Image.fromarray(((c["fixed4__png"] > 0) * 255).astype(np.uint8)).save(tmp_path / "s" / "bin.png")
+    torch.save([{"id": "bin", "bboxes": [[0, 0, 1, 1]], "segment_indices": [1], "clusters": np.array([7])}], tmp_path / "cb.pth")
+    extract.extract_semantic_segmentations(str(tmp_path / "s"), str(tmp_path / "cb.pth"), str(tmp_path / "semb"))
+    assert set(np.unique(np.array(Image.open(tmp_path / "semb" / "bin.png"))).tolist()) <= {0, 7}
