@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-3 GPU session script (run through gpurun): kernel labs, PMC passes, GPU test-suite, bench lines.  Logs -> gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+REPO_DIR=$PWD
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
+pmc_pass() {   # pmc_pass <tag> <counters...> -- <command...>
+  local tag=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  rm -rf gpurun_out/pmc_$tag && mkdir -p gpurun_out/pmc_$tag
+  (cd /tmp && timeout 300 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace -d $REPO_DIR/gpurun_out/pmc_$tag -o pmc -- "$@" > $REPO_DIR/gpurun_out/pmc_$tag/run.log 2>&1)
+  local db=$(find gpurun_out/pmc_$tag -name "*.db" | head -1)
+  if [ -n "$db" ]; then python scripts/rocpd_pmc_multi.py $db 2 > gpurun_out/pmc_$tag.csv; rm -rf gpurun_out/pmc_$tag; head -4 gpurun_out/pmc_$tag.csv | cut -c1-400; else echo "pmc $tag: no db"; tail -5 gpurun_out/pmc_$tag/run.log; fi
+}
+for STAGE in "$@"; do
+  case $STAGE in
+    lab)   # attention variants A/B on the bench shapes
+      for ARGS in "290 901 6 1" "255 1024 6 1" "16 3601 12 0"; do
+        timeout 300 scripts/probes/attn_lab $ARGS -1 5 >> gpurun_out/attn_lab.log 2>&1; echo "lab($ARGS) exit $?"
+        [ -x scripts/probes/attn_lab_scalar ] && { echo "--- scalar softmax build (-fno-slp-vectorize)" >> gpurun_out/attn_lab.log; timeout 300 scripts/probes/attn_lab_scalar $ARGS -1 5 >> gpurun_out/attn_lab.log 2>&1; echo "lab_scalar($ARGS) exit $?"; }
+      done
+      cat gpurun_out/attn_lab.log;;
+    lab1)   # main shape only, both builds; LAB_ONLY=<variant> restricts
+      rm -f gpurun_out/attn_lab1.log
+      for BIN in attn_lab attn_lab_scalar; do
+        echo "--- $BIN" >> gpurun_out/attn_lab1.log
+        timeout 120 scripts/probes/$BIN ${LAB_SHAPE:-290 901 6 1} ${LAB_ONLY:--1} 5 2>&1 | grep -v "ablation / not expected" >> gpurun_out/attn_lab1.log; echo "$BIN exit $?"
+      done
+      cat gpurun_out/attn_lab1.log;;
+    lab_clock) timeout 120 scripts/probes/attn_lab_clock ${LAB_SHAPE:-290 901 6 1} ${LAB_ONLY:--1} 3 2>&1 | grep -v "vs product" > gpurun_out/attn_lab_clock.log; echo "lab_clock exit $?"; cat gpurun_out/attn_lab_clock.log;;
+    lab_pmc)   # counters of single variants (LAB_VARIANTS="0 8"), shape 290 x 901 x 6 planar
+      for V in ${LAB_VARIANTS:-0 8}; do
+        pmc_pass lds_v$V SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT -- $REPO_DIR/scripts/probes/attn_lab 290 901 6 1 $V 2
+        pmc_pass wait_v$V SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE -- $REPO_DIR/scripts/probes/attn_lab 290 901 6 1 $V 2
+        pmc_pass l2_v$V TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -- $REPO_DIR/scripts/probes/attn_lab 290 901 6 1 $V 2
+      done;;
+    host_enqueue) timeout 600 python scripts/debug/host_enqueue.py > gpurun_out/host_enqueue.log 2>&1; echo "host_enqueue exit $?"; cat gpurun_out/host_enqueue.log;;
+    tests) timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -x 2>&1 | tail -80 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
+    tests_all) timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
+    tests_attn) timeout 900 python -m pytest tests -m gpu -q --timeout 600 -rf --tb=short -k "attention or vit" 2>&1 | tail -40 > gpurun_out/pytest_attn.log; tail -25 gpurun_out/pytest_attn.log;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -4 gpurun_out/smoke.log;;
+    bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
+    *) echo "unknown stage $STAGE";;
+  esac
+done
