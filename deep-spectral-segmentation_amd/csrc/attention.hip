@@ -4,9 +4,8 @@
 // extract/extract.py:94):   attn = softmax((q @ k^T) * scale) ; x = (attn @ v).transpose(1,2).reshape(B,T,C)
 // The [h, T, T] score matrix is never materialised (flash-style online softmax).
 //
-// One kernel, attn_fwd4 (design notes and the measurements behind them at its definition): the qkv tensor is read in
-// place - interleaved [B,T,3,h,64] or DSS_PLANAR64 -, K/V tiles of 64 keys are staged through registers into
-// double-buffered LDS, and every wave runs, per 32 keys,
+// One kernel, attn_fwd_kernel: the qkv tensor is read in place - interleaved [B,T,3,h,64] or DSS_PLANAR64 -, K/V stages
+// of 64 keys arrive in LDS by LDS-DMA, and every wave runs, per 32 keys,
 //        S^T[key][q]  = mfma_32x32x16( K-fragment , Q-fragment )      (contraction over dh = 64)
 //        online softmax down each lane's own query column (lane-local: no cross-lane traffic on the common path)
 //        O^T[dh][q]  += mfma_32x32x16( V^T-fragment , P^T-fragment )  (contraction over 32 keys)
@@ -26,10 +25,9 @@
 // transposed LDS read of V (ds_read_b64_tr_b16) delivers V^T fragments in exactly that key order.
 #include "common.h"
 
-// scripts/probes/attn_clock_probe.hip includes this file with DSS_ATTN_CLOCK defined to read the shader clock the chip
-// sustains INSIDE the kernel, scripts/probes/attn_timeline_probe.hip with DSS_ATTN_TIMELINE to record when and where
-// every workgroup ran; in the library the hooks compile to nothing.
-#ifdef DSS_ATTN_CLOCK   // shader clock sustained inside the kernel: s_memtime (shader cycles) vs s_memrealtime, summed over all workgroups
+// scripts/probes/attn_lab.hip includes this file with DSS_ATTN_CLOCK defined to read the shader clock the chip sustains
+// INSIDE the kernel (s_memtime vs s_memrealtime summed over all workgroups); in the library the hooks compile to nothing.
+#ifdef DSS_ATTN_CLOCK
 __device__ unsigned long long dss_clock_buf[4];
 #define DSS_CLOCK_BEGIN                                                                       \
   const bool clk_on = threadIdx.x == 0;                                                       \
@@ -41,19 +39,6 @@ __device__ unsigned long long dss_clock_buf[4];
     atomicAdd(&dss_clock_buf[1], wall_clock64() - clk_r0);                                    \
     atomicAdd(&dss_clock_buf[2], 1ull);                                                       \
   }
-#elif defined(DSS_ATTN_TIMELINE)   // per-workgroup start / end (100 MHz counter) and placement (HW_ID, XCC_ID)
-__device__ unsigned long long* dss_timeline_buf;   // [gridDim.x][4]
-#define DSS_CLOCK_BEGIN                                                                       \
-  unsigned long long tl_r0 = 0;                                                               \
-  if (threadIdx.x == 0) tl_r0 = wall_clock64();
-#define DSS_CLOCK_END                                                                         \
-  if (threadIdx.x == 0) {                                                                     \
-    unsigned hw, xcc;                                                                         \
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                          \
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                        \
-    unsigned long long* t = dss_timeline_buf + 4ull * blockIdx.x;                             \
-    t[0] = tl_r0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;                               \
-  }
 #else
 #define DSS_CLOCK_BEGIN
 #define DSS_CLOCK_END
@@ -63,14 +48,11 @@ namespace dss {
 
 static constexpr int DH = 64;  // head dim of every DINO ViT
 typedef __attribute__((address_space(3))) void* lds_as3_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// ---- LDS tile layouts (both conflict-free, checked with SQ_LDS_BANK_CONFLICT) -----------------------------------------
-//   * K tile row-major, row stride 144 B: the ds_read_b128 operand reads (16 lanes = 16 rows) land on 16 distinct
-//     4-bank slots.
-//   * V tile row-major, row stride 192 B, read with ds_read_b64_tr_b16: inside a 16-lane group lane i supplies the
-//     address of (row i>>2, cols 4*(i&3)..+3) of a [4 keys x 16 dh] block and receives column i (verified on hardware,
-//     scripts/probes/tr16_probe.hip) - the hardware transpose turns row-major V into the V^T fragment the P.V MFMA
-//     needs; 192 B puts the 4 rows of a block on disjoint bank quarters.
+// ds_read_b64_tr_b16 pair: inside a 16-lane group lane i supplies the address of (row i>>2, cols 4*(i&3)..+3) of a
+// [4 keys x 16 dh] block and receives column i (verified on hardware, scripts/probes/tr16_probe.hip) - the hardware
+// transpose turns row-major V into the V^T fragment the P.V MFMA needs.
 template <class T>
 __device__ __forceinline__ typename vec8<T>::type lds_read_tr_pair(const T* p_lo, const T* p_hi) {
   typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -80,9 +62,6 @@ __device__ __forceinline__ typename vec8<T>::type lds_read_tr_pair(const T* p_lo
   const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(typename vec8<T>::type, c);
 }
-
-static constexpr int KLD = 72;   // halves per K row in LDS (144 B)
-static constexpr int VLD = 96;   // halves per V row in LDS (192 B)
 
 // Cross-half (lane ^ 32) exchange on the VALU (v_permlane32_swap), no LDS round trip: returns, in every lane,
 // max(x[lane & 31], x[32 + (lane & 31)]).
@@ -102,56 +81,15 @@ __device__ __forceinline__ float half_pair_sum(float x) {
   return __uint_as_float(lo) + __uint_as_float(hi);
 }
 
-
-// The common path of the online softmax, in place: s becomes p = exp2(s c - m c) against the OLD running max; returns
-// the two interleaved partial row sums.  Packed fp32 (8 v_pk_fma_f32 + 16 v_exp_f32 + 9 v_pk_add_f32); the scalar form
-// (DSS_ATTN_SCALAR_SOFTMAX, lab builds with -fno-slp-vectorize: 16 v_fma + 16 v_exp + 16 v_add) exists to measure what the
-// packed instructions cost beside MFMAs.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t diet_softmax(f32x16& s, float c, float mc) {
-#ifdef DSS_ATTN_SCALAR_SOFTMAX
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -mc));
-#pragma unroll
-  for (int i = 0; i < 16; i += 4) { a0 += s[i]; a1 += s[i + 1]; a2 += s[i + 2]; a3 += s[i + 3]; }
-  return f32x2_t{a0 + a2, a1 + a3};
-#else
-  const f32x2_t c2 = {c, c};
-  f32x2_t nmc2 = {-mc, -mc}, acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const f32x2_t sv = {s[2 * i], s[2 * i + 1]};
-    const f32x2_t e = __builtin_elementwise_fma(sv, c2, nmc2);
-    s[2 * i] = __builtin_amdgcn_exp2f(e[0]);
-    s[2 * i + 1] = __builtin_amdgcn_exp2f(e[1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    acc0 += f32x2_t{s[2 * i], s[2 * i + 1]};
-    acc1 += f32x2_t{s[2 * i + 2], s[2 * i + 3]};
-  }
-  return acc0 + acc1;
-#endif
-}
-
-
-// FLAGS & 16 form: the MFMA chain already delivered s - m in the log2 domain; p = exp2(.) in place and the row sums.
-__device__ __forceinline__ f32x2_t exp_rowsum(f32x16& s) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-#pragma unroll
-  for (int i = 0; i < 16; i += 4) { a0 += s[i]; a1 += s[i + 1]; a2 += s[i + 2]; a3 += s[i + 3]; }
-  return f32x2_t{a0 + a2, a1 + a3};
-}
-
-
-// The same with the instruction ORDER pinned (scripts/probes/simd_model_probe.hip: beside four waves' MFMAs the SIMD runs
-// 16 v_exp + 16 v_add in 339 cycles per 8 MFMAs when the adds follow the exps as four chains - hipcc's order -, in 307
-// when every add trails its exp by a few instructions; packed fp32 adds / v_dot2 cost 390-400).  Inline asm because the
-// scheduler regroups builtins; the first statement carries the MFMA -> VALU wait states hipcc would have inserted (it
-// does not model hazards across an asm boundary).  x[] are the 16 scores of one lane (s - m, log2 domain).
+// ---- the common path of the online softmax -----------------------------------------------------------------------------
+// The score chain already delivered s - m in the log2 domain (see the kernel): p = exp2(.) in place plus the two
+// interleaved partial row sums.  Instruction ORDER matters more than instruction count here.  What
+// scripts/probes/simd_model_probe.hip measured with four waves per SIMD, cycles per 8 MFMAs (256 cycles of matrix pipe):
+//   16 v_exp alone 264 | 16 v_exp then 16 v_add as four chains (hipcc's order) 339 | every add a few instructions behind
+//   its exp 307 | 8 v_pk_add_f32 instead of the 16 adds 397 | 8 v_dot2_f32_f16 388 | with 16 v_fma in front of the exps 389
+// (packed fp32 and VOP3P ops are the expensive ones beside other waves' MFMAs: round 2's v_pk_fma / v_pk_add softmax cost
+// 464).  Inline asm because the scheduler regroups builtins; the first statement carries the MFMA -> VALU wait states
+// hipcc would have inserted (it does not model hazards across an asm boundary).
 __device__ __forceinline__ f32x2_t exp_rowsum_ordered(f32x16& s) {
   float x0 = s[0], x1 = s[1], x2 = s[2], x3 = s[3], x4 = s[4], x5 = s[5], x6 = s[6], x7 = s[7];
   float x8 = s[8], x9 = s[9], x10 = s[10], x11 = s[11], x12 = s[12], x13 = s[13], x14 = s[14], x15 = s[15];
@@ -177,67 +115,67 @@ __device__ __forceinline__ f32x2_t exp_rowsum_ordered(f32x16& s) {
   s[8] = x8; s[9] = x9; s[10] = x10; s[11] = x11; s[12] = x12; s[13] = x13; s[14] = x14; s[15] = x15;
   return f32x2_t{a0 + a2, a1 + a3};
 }
+// the same arithmetic in plain C++ (ragged key halves only: their scores may be -inf, order is irrelevant there)
+__device__ __forceinline__ f32x2_t exp_rowsum(f32x16& s) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) { a0 += s[i]; a1 += s[i + 1]; a2 += s[i + 2]; a3 += s[i + 3]; }
+  return f32x2_t{a0 + a2, a1 + a3};
+}
 
 // ================================================================================================
-// attn_fwd4: occupancy instead of choreography.  What round 2 measured on MI355X (scripts/probes/overlap_probe.hip,
-// profiles/r02_attention_probes.txt) and what it means at head dim 64, where the online softmax costs ~45 VALU
-// instructions per 8 MFMAs:
-//   * ONE wave issues at most one VALU instruction every ~5-7 cycles (a v_exp_f32 every ~9), whatever else the SIMD does;
-//     a SIMD reaches its VALU rate (2.7 cycles per simple op, 4.7 per v_exp, this mix ~3.2) only with 3-4 resident waves;
-//   * the matrix pipe is indifferent to VALU traffic from OTHER waves (16 MFMAs: 549 cycles alone, 553 beside a softmax);
-//   * the loop body below on registers only runs 509 / 385 / 334 / 307 cycles per 8 MFMAs (256 cycles of matrix pipe) per
-//     SIMD at 1 / 2 / 3 / 4 waves per SIMD.
-// Two kernels built on two waves per SIMD lost to that arithmetic and were deleted: round 1's 4-wave x 64-query kernel
-// (182 VGPRs; 566-600 us on the 290-image bench shape) and an 8-wave ping-pong kernel that kept one wave of every SIMD in
-// a pure-MFMA phase while its partner ran the softmax (223-250 VGPRs, 4 barriers per key tile: 680-740 us - the single
-// softmax wave per SIMD issues too slowly to keep up with the matrix phase, so the phases added up instead of hiding
-// each other).  Here a wave owns 32 queries instead of 64 - O^T is 32 registers, the kernel fits 128 - so FOUR waves
-// share a SIMD (two 8-wave workgroups per CU) and the hardware interleaves one wave's MFMAs with the others' softmax:
-// 541 us, 0.67 PFLOP/s.  The price: every K / V^T fragment read from LDS feeds one MFMA instead of two.
-//   * workgroup = 8 waves x 32 queries = 256 queries of one (image, head), 1-D XCD-aware grid (the query blocks of one
-//     (image, head) share an XCD, so K/V come out of its L2: PMC traffic == algorithmic bytes); K/V tiles of 64 keys are
-//     staged once per workgroup through registers into double-buffered LDS, one barrier per tile;
-//   * per 32 keys: S^T = K.Q^T (4 MFMAs from the inline constant 0), VALU-diet softmax IN PLACE - 8 v_pk_fma_f32 +
-//     16 v_exp_f32 + 9 v_pk_add_f32 + 8 v_cvt_pk: the probabilities are computed against the OLD running max straight
-//     away and their row sums are the rescale test (every p <= 2^6 is implied by sum(p) <= 2^6; a first tile, m = -1e30,
-//     or an overflow gives inf/NaN, which fails `sum <= 2^6` as well) - no max tree, no cross-lane exchange; then
-//     O^T += V^T.P^T (4 MFMAs);
-//   * when the test fires (wave-uniform ballot; first tile, or a row maximum that grew by more than 2^6) the raw scores
-//     are recomputed by re-issuing the 4 MFMAs - their registers hold the probabilities by then, and spare registers for
-//     a copy would cost the fourth wave - and take the exact path: new max, rescale of O and l, probabilities again;
-//   * the ragged last key tile is peeled out of the main loop (instruction issue is the scarce resource: the main loop
-//     carries no per-half conditions); its keys past the end are masked through the MFMA accumulator's INITIAL value
-//     (-inf in their rows, 0 elsewhere - the MFMA adds it for free).
-// Where the rest goes (profiles/r02_attention_probes.txt): the register-only body runs 307 cycles per half per SIMD, the
-// kernel 578.  Ablations of this kernel: fragments from registers instead of LDS -4 %, no restaging -4 %, no restaging
-// and no barrier -9 %; the timeline probe shows 1.61 of the 2 workgroup slots of a CU occupied on average - 6.5 us pass
-// between the end of a workgroup (its output stores drain before its registers and LDS are released) and the start of
-// its successor, 16 % of a 40 us workgroup.  Tried against that and measured slower: workgroups that walk several work
-// items (2 / 4 / 8 / all of a CU slot's ~14: +1 ... +20 %; item times vary 23-74 us with what the neighbours are doing, so
-// static walks lose to the hardware dispatcher what they save on the gap), a PERSISTENT grid of two workgroups per CU
-// that draw items dynamically from per-XCD ticket counters, the next ticket fetched while the current item runs
-// (bit-identical results; 540 vs 535 us at T = 901, 105 vs 49 us at T = 197 - the "gap" is the item's own prologue and
-// drain, not dispatch latency, and only a second resident workgroup hides it), a three-tile LDS ring with the score
-// MFMAs of the next half issued ahead of this half's softmax (128 VGPRs + spills: 3x slower), and the same software
-// pipeline done properly at two waves per SIMD - 64 queries per wave as two independent 32-query tiles A / B, per 32 keys
-// the steps {S_B = K.Q_B, O_B += V.P_B || softmax A} and {O_A += V.P_A, S_A(next) = K.Q_A || softmax B} with the
-// fragment reads of the next step issued first, every K / V^T fragment feeding two MFMAs, a 3-deep LDS ring with one
-// mid-tile barrier; 250 VGPRs, no spills, hipcc interleaves each step's 8 MFMAs with its ~45 VALU instructions
-// (sched_group_barrier), results bit-identical to this kernel: 588 vs 571 us on the same box.  Neither pipe is
-// saturated in either kernel (a SIMD retires one instruction per ~10 cycles); what is left needs instruction-level
-// control of issue and dependency stalls that the compiler does not give.
-// ABL (scripts/probes/attn_lab.hip only; the library instantiates 0): 1 = the K/V tiles are staged once, no restaging and
-// no barrier inside the loop (every tile reads tile 0: wrong results, same instruction stream otherwise); 2 = the
-// K / V^T fragments are read from LDS once and kept in registers (no LDS reads inside the loop); 4 = no output stores.
-template <class T, int ABL = 0>
-__global__ __launch_bounds__(512, 4) void attn_fwd4_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
-                                                           int heads, int nb, int nqb, float scale_log2,
-                                                           int planar) {
+// attn_fwd_kernel.  Workgroup = 8 waves x 32 queries = 256 queries of one (image, head); 1-D XCD-aware grid (the query
+// blocks of one (image, head) share an XCD, so K/V come out of its L2: PMC traffic == algorithmic bytes); <= 128 VGPRs,
+// FOUR waves per SIMD (two workgroups per CU): the hardware overlaps one wave's MFMAs with the others' softmax - round 2
+// measured 64-query waves, ping-pong pairs and in-wave software pipelines at two waves per SIMD, all slower.
+//
+// Round 3 (scripts/probes/attn_lab.hip, profiles/r03_attention_lab.txt; 290 x 901 x 6: 517-531 -> 444-453 us, 16 x 3601 x 12:
+// 735-762 -> 636-642 us = 1.0 PFLOP/s):
+//   * K/V stages by LDS-DMA.  A stage = 64 keys of K and of V as UNPADDED 128-byte rows, two stage buffers.  One
+//     global_load_lds_dwordx4 wave-instruction moves 1 KB = 8 rows: lane i fetches 16-byte chunk c of row i >> 3 and the
+//     hardware puts it at position i & 7 of that row - the swizzle lives in the SOURCE address (the LDS image of a DMA is
+//     lane-linear), the reads apply the same involution:
+//        K row r: chunk c at position c ^ ((r >> 1) & 7) - the 16 lanes of a ds_read_b128 service group (16 distinct
+//                 rows, one chunk index) land on 16 distinct 16-byte slots of the 256-byte bank row;
+//        V row r: chunk c at position c ^ (4 * ((r >> 1) & 1)) - the four rows of a [4 keys x 16 dh] transpose block
+//                 land on the four bank quarters.  (SQ_LDS_BANK_CONFLICT: 0 for both.)
+//     Every 8 lanes cover one full 128-byte line of the source: the DMA is perfectly coalesced for both qkv layouts.  No
+//     staging registers, no ds_write pass; the pieces of stage s + 1 are in flight during stage s:
+//        s_waitcnt vmcnt(0) (own pieces of stage s) ; s_barrier (raw: nothing else crosses waves) ; first half of
+//        stage s ; issue stage s + 1 (between the halves: the 16 DMA instructions of a workgroup do not collide with the
+//        fragment-read burst that follows the barrier) ; second half.
+//     Keys past the end of the sequence: the DMA source row is clamped to the last key (finite data), the scores are
+//     masked through the accumulator's initial value (-inf in their rows - the MFMA adds it for free).
+//   * log2-domain logits.  Q is multiplied by scale * log2(e) once per workgroup (one rounding to T, what the K
+//     projection's own rounding already costs), and the running offset -m rides in on the accumulator of the score
+//     chain's first MFMA: all 16 accumulator registers of a lane belong to ONE query, so a 16-register block holding -m
+//     (rewritten only on the rare rescale path) makes the chain deliver s - m.  The softmax common path is exp2 + row sum:
+//     no multiply, no subtract (the v_fma per score of round 2 is gone), instruction order pinned (exp_rowsum_ordered).
+//   * the probabilities are computed against the OLD running max straight away and their row sums are the rescale test
+//     (every p <= 2^6 is implied by sum(p) <= 2^6; an overflow gives inf/NaN, which fails `sum <= 2^6` as well) - no max
+//     tree, no cross-lane exchange on the common path.  When the wave-uniform ballot fires (a row maximum that grew by
+//     more than 2^6) the raw scores are recomputed by re-issuing the 4 MFMAs from a zero accumulator and the exact path
+//     runs: new max, rescale of O and l, probabilities again.  The first half of a pass has no running max: it takes
+//     the exact path directly.
+//   * the output leaves as full 128-byte rows: O^T goes through a private 4 KB LDS patch per wave (stage buffer 0, behind
+//     a barrier), 8 lanes store one row - 4 stores of 16 B per lane instead of 8 scattered 8-byte pieces.
+// What the ablations say is left (same lab, same shape, 444-453 us): without stage barriers and DMA 421-434, fragments
+// from registers instead of LDS another ~40; a persistent grid with per-XCD ticket queues and a K/V stream that runs on
+// across work items was built and measured equal (483-499 vs 477-502 us before the softmax change): with every slot
+// always filled the four waves of a SIMD contend more, what the idle slots cost is what they give back to the
+// neighbours.  The shader clock inside the workgroups is 1.79-1.87 GHz (1.95-1.97 with LDS, DMA and stores ablated).
+//
+// FLAGS (lab only, results wrong; the library instantiates 0): 4 = no stage barrier, 8 = no DMA inside the loop.
+template <class T, int FLAGS>
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+                                                          int heads, int nb, int nqb, float scale_log2, int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) T Ks[2][64 * KLD];
-  __shared__ __attribute__((aligned(16))) T Vs[2][64 * VLD];
+  constexpr int SK = 64;               // keys per stage
+  constexpr int OPB = SK * 128;        // bytes per operand per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2][2][OPB];   // [stage buffer][K | V]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hh = lane >> 5;
@@ -266,230 +204,6 @@ __global__ __launch_bounds__(512, 4) void attn_fwd4_kernel(const T* __restrict__
   const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
   DSS_CLOCK_BEGIN
 
-  V8 qf[4];
-  {
-    int qa = q0 + li;
-    qa = qa < Tn ? qa : Tn - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const V8*>(base + (long)qa * rs + 16 * s + 8 * hh);
-  }
-  const int srow = tid >> 3, scol = (tid & 7) * 8;
-  V8 kreg, vreg;
-  auto stage_load = [&](int kt) {
-    const int key = kt * 64 + srow;
-    if (key < Tn) {
-      const T* p = base + (long)key * rs + scol;
-      kreg = *reinterpret_cast<const V8*>(p + koff);
-      vreg = *reinterpret_cast<const V8*>(p + 2 * koff);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { kreg[i] = (T)0.f; vreg[i] = (T)0.f; }
-    }
-  };
-  auto stage_write = [&](int buf) {
-    *reinterpret_cast<V8*>(&Ks[buf][srow * KLD + scol]) = kreg;
-    *reinterpret_cast<V8*>(&Vs[buf][srow * VLD + scol]) = vreg;
-  };
-
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m = -1.0e30f, mc = -1.0e30f * scale_log2;
-  f32x2 l2 = {0.f, 0.f};                   // this lane's partial row sums (two interleaved halves of its keys)
-  const float c = scale_log2;
-  const int nkt = (Tn + 63) / 64;
-  const int tr_row = 4 * hh + ((lane & 15) >> 2);
-  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-
-  // one 32-key half: scores, diet softmax in place, P.V.  `tail`: keys past the end of the sequence are masked through
-  // the accumulator's initial value (last half only); full halves start the MFMA chain from the inline constant 0.
-  // (Two separate chains on purpose: one chain behind a select would materialise sixteen zeros per half.)
-  V8 abl_k, abl_v;                             // ABL & 2: one K and one V^T fragment, read once, feed every MFMA
-  auto half_block = [&](const T* kbuf, const T* vbuf, int half, int key0, bool tail) {
-    const T* krow = kbuf + (half * 32 + li) * KLD + 8 * hh;
-    auto kfrag = [&](int sl) { return (ABL & 2) ? abl_k : *reinterpret_cast<const V8*>(krow + 16 * sl); };
-    auto scores = [&]() {
-      f32x16 s;
-      if (tail) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? 0.f : -INFINITY;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(kfrag(sl), qf[sl], s);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(kfrag(sl), qf[sl], s);
-      }
-      return s;
-    };
-    f32x16 s = scores();
-    // ---- diet softmax, in place: s becomes p = exp2(s c - m c) against the OLD running max ----
-    f32x2 acc0 = diet_softmax(s, c, mc);
-    // every p <= 2^6 is implied by both partial sums <= 2^6; inf / NaN (first tile: m = -1e30) fail the test too
-    if (__builtin_amdgcn_ballot_w64(!(acc0[0] <= 64.0f && acc0[1] <= 64.0f)) != 0) {   // wave-uniform, rare
-      s = scores();
-      float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])),
-                           fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
-      mx = half_pair_max(mx);
-      const float m_new = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);   // m = -1e30 initially -> alpha = 0
-      m = m_new;
-      mc = m_new * c;
-      l2 *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      acc0 = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -mc));
-        s[r + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], c, -mc));
-        acc0 += f32x2{s[r], s[r + 1]};
-      }
-    }
-    l2 += acc0;
-    V8 pb0, pb1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pb0[e] = from_f32<T>(s[e]);
-      pb1[e] = from_f32<T>(s[8 + e]);
-    }
-    const T* vbase = vbuf + (half * 32 + tr_row) * VLD + tr_col;
-    if (ABL & 2) {
-      o0 = mfma32x32x16(abl_v, pb0, o0);
-      o1 = mfma32x32x16(abl_v, pb0, o1);
-      o0 = mfma32x32x16(abl_v, pb1, o0);
-      o1 = mfma32x32x16(abl_v, pb1, o1);
-      return;
-    }
-    {
-      const V8 v0 = lds_read_tr_pair<T>(vbase, vbase + 8 * VLD);
-      const V8 v1 = lds_read_tr_pair<T>(vbase + 32, vbase + 8 * VLD + 32);
-      o0 = mfma32x32x16(v0, pb0, o0);
-      o1 = mfma32x32x16(v1, pb0, o1);
-    }
-    {
-      const V8 v0 = lds_read_tr_pair<T>(vbase + 16 * VLD, vbase + 24 * VLD);
-      const V8 v1 = lds_read_tr_pair<T>(vbase + 16 * VLD + 32, vbase + 24 * VLD + 32);
-      o0 = mfma32x32x16(v0, pb1, o0);
-      o1 = mfma32x32x16(v1, pb1, o1);
-    }
-  };
-
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
-  if (ABL & 2) {
-    abl_k = *reinterpret_cast<const V8*>(&Ks[0][li * KLD + 8 * hh]);
-    abl_v = lds_read_tr_pair<T>(&Vs[0][tr_row * VLD + tr_col], &Vs[0][(tr_row + 8) * VLD + tr_col]);
-  }
-  // full tiles: straight-line code, no per-half conditions (instruction issue is the scarce resource of this kernel)
-  const int nfull = Tn / 64;
-  int kt = 0;
-  for (; kt < nfull; ++kt) {
-    const int buf = (ABL & 1) ? 0 : (kt & 1);
-    if (!(ABL & 1) && kt + 1 < nkt) stage_load(kt + 1);
-    if (active) {
-      half_block(&Ks[buf][0], &Vs[buf][0], 0, kt * 64, false);
-      half_block(&Ks[buf][0], &Vs[buf][0], 1, kt * 64 + 32, false);
-    }
-    if (!(ABL & 1)) {
-      if (kt + 1 < nkt) stage_write(buf ^ 1);
-      __syncthreads();
-    }
-  }
-  if (kt < nkt && active) {                    // the ragged last tile: 1..63 real keys
-    const int buf = kt & 1, key0 = kt * 64;
-    half_block(&Ks[buf][0], &Vs[buf][0], 0, key0, key0 + 32 > Tn);
-    if (key0 + 32 < Tn) half_block(&Ks[buf][0], &Vs[buf][0], 1, key0 + 32, true);
-  }
-  float l = l2[0] + l2[1];
-  DSS_CLOCK_END
-
-  if (!active) return;
-  const float lsum = half_pair_sum(l);                  // the two half-waves hold disjoint keys of each query
-  const int q = q0 + li;
-  if (ABL & 4) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(o0[r] * lsum), "v"(o1[r]));
-    return;
-  }
-  if (q < Tn) {
-    const float inv = 1.0f / lsum;
-    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      V4 a, cc;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = from_f32<T>(o0[4 * g + i] * inv);
-        cc[i] = from_f32<T>(o1[4 * g + i] * inv);
-      }
-      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
-      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = cc;
-    }
-  }
-}
-
-
-// ================================================================================================
-// attn_fwd5: the same arithmetic as attn_fwd4 (identical fragments, key order and softmax: results are bit-identical),
-// K/V tiles brought in by LDS-DMA instead of through registers.
-//   * a stage = SK keys (64 or 128) of K and of V as UNPADDED 128-byte rows; two stage buffers.  One
-//     global_load_lds_dwordx4 wave-instruction moves 1 KB = 8 rows: lane i fetches 16-byte chunk c of row i >> 3 and
-//     the hardware puts it at position i & 7 of that row - the swizzle lives in the SOURCE address (the LDS image of
-//     a DMA is lane-linear), the reads apply the same involution:
-//        K row r: chunk c at position c ^ ((r >> 1) & 7) - the 16 lanes of a ds_read_b128 service group (16 distinct
-//                 rows, one chunk index) land on 16 distinct 16-byte slots of the 256-byte bank row;
-//        V row r: chunk c at position c ^ (4 * ((r >> 1) & 1)) - the four rows of a [4 keys x 16 dh] transpose block
-//                 land on the four bank quarters (the job the 192-byte row stride did in attn_fwd4).
-//     Every 8 lanes cover one full 128-byte line of the source: the DMA is perfectly coalesced for both layouts.
-//   * no staging registers, no ds_write pass, and the loads of stage s + 1 are in flight during all of stage s:
-//     per stage  s_waitcnt vmcnt(0) (own pieces of stage s, issued a stage ago) ; s_barrier (raw: no fence, nothing
-//     else crosses waves) ; issue stage s + 1 ; compute stage s.
-//   * keys past the end of the sequence: the DMA source row is clamped to the last key (finite data), the scores are
-//     masked through the accumulator's initial value exactly as in attn_fwd4.
-// NW = waves per workgroup (32 queries each).  FLAGS (lab switches): 1 = O^T through an LDS patch, stored as full 128-byte
-// rows; 2 = those row stores non-temporal; 4 = no stage barrier, 8 = no DMA inside the loop (ablations: wrong results);
-// 64 = the first half of a pass goes straight to the exact path; 128 = a stage's DMA is issued
-// between its halves; 32 (with 16) = softmax instruction order pinned by inline asm; 16 = log2-domain logits: Q pre-multiplied by scale * log2(e) once, the running offset -m enters through the accumulator.
-template <class T, int SK, int FLAGS, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
-                                                           int heads, int nb, int nqb, float scale_log2,
-                                                           int planar) {
-  typedef typename vec8<T>::type V8;
-  typedef typename vec4<T>::type V4;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr int NH = SK / 32;          // 32-key halves per stage
-  constexpr int PW = SK / (8 * NW);    // 1 KB pieces per operand per wave per stage
-  constexpr int OPB = SK * 128;        // bytes per operand per stage
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2][2][OPB];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, hh = lane >> 5;
-  int qblk, group;
-  {
-    const int id = blockIdx.x, groups = heads * nb, g8 = groups & ~7;
-    if (id < nqb * g8) {
-      const int xcd = id & 7, slot = id >> 3;
-      group = (slot / nqb) * 8 + xcd;
-      qblk = slot % nqb;
-    } else {
-      const int r = id - nqb * g8;
-      group = g8 + r / nqb;
-      qblk = r % nqb;
-    }
-  }
-  const int head = group % heads, b = group / heads;
-  const long plane = (long)nb * Tn * DH;
-  const long rs = planar ? DH : 3L * heads * DH;                    // row stride (halves)
-  const long koff = planar ? heads * plane : (long)heads * DH;      // q -> k ; q -> v is twice that
-  const T* base = planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
-  const int q0 = qblk * (32 * NW) + wave * 32;
-  const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
-  DSS_CLOCK_BEGIN
-
   // ---- K/V stage DMA --------------------------------------------------------------------------------------------
   const unsigned rb = (unsigned)(rs * 2);                           // row bytes (< 2^13)
   // (wave-uniform by construction; readfirstlane makes it provable, so the pointers live in SGPR pairs)
@@ -502,25 +216,22 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restri
   const unsigned char* vsrc = uniform_ptr(base + 2 * koff);
   const unsigned lds0 = (unsigned)(size_t)(lds_as3_t)(&lds[0][0][0]);
   auto dma16 = [&](const unsigned char* src, unsigned off, unsigned dst) {
+    // inline asm, not the builtin: hipcc then neither serialises the LDS reads behind it nor counts it (see the Q loads)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst), "v"(off), "s"(src) : "memory");
   };
-  auto issue = [&](int s) {
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const int p = wave * PW + j;                                  // piece (8 rows) of the stage, wave-uniform
-      const int r = 8 * p + (lane >> 3);                            // row inside the stage
-      int key = s * SK + r;
-      key = key < Tn ? key : Tn - 1;
-      const unsigned rowoff = (unsigned)key * rb;
-      const unsigned kc = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
-      const unsigned vc = (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2));
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s & 1) * 2 * OPB + p * 1024));
-      dma16(ksrc, rowoff + 16u * kc, dst);
-      dma16(vsrc, rowoff + 16u * vc, dst + OPB);
-    }
+  auto issue = [&](int s) {                                         // wave w moves piece w (8 rows) of K and of V
+    const int r = 8 * wave + (lane >> 3);                           // row inside the stage
+    int key = s * SK + r;
+    key = key < Tn ? key : Tn - 1;
+    const unsigned rowoff = (unsigned)key * rb;
+    const unsigned kc = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+    const unsigned vc = (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2));
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s & 1) * 2 * OPB + wave * 1024));
+    dma16(ksrc, rowoff + 16u * kc, dst);
+    dma16(vsrc, rowoff + 16u * vc, dst + OPB);
   };
   issue(0);
 
@@ -534,24 +245,19 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restri
     // s_waitcnt vmcnt(3..0) in front of the first MFMAs INSIDE the loop, and since the hardware counter also holds the
     // LDS-DMA pieces hipcc cannot see (inline asm), that wait would drain the next stage's DMA in every iteration.
     asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
-    if (FLAGS & 16) {   // log2-domain logits straight out of the MFMA: Q <- Q * scale * log2(e), rounded once
+    // log2-domain logits straight out of the MFMA: Q <- Q * scale * log2(e), rounded once
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s][e] = from_f32<T>(to_f32<T>(qf[s][e]) * scale_log2);
-    }
+      for (int e = 0; e < 8; ++e) qf[s][e] = from_f32<T>(to_f32<T>(qf[s][e]) * scale_log2);
   }
 
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m = -1.0e30f, mc = -1.0e30f * scale_log2;
-  f32x2 l2 = {0.f, 0.f};
-  const float c = (FLAGS & 16) ? 1.0f : scale_log2;
-  if (FLAGS & 16) mc = m;
-  // FLAGS & 16: the running offset rides in on the MFMA accumulator (all 16 registers of a lane belong to ONE query and
-  // hold -m): the score chain delivers s - m, the softmax is exp2 + row sum only; rewritten on the rare rescale path
-  f32x16 cm;
+  float m = -1.0e30f;
+  f32x2_t l2 = {0.f, 0.f};                 // this lane's partial row sums (two interleaved halves of its keys)
+  f32x16 cm;                               // -m in all 16 registers: the score chain's initial accumulator
 #pragma unroll
   for (int r = 0; r < 16; ++r) cm[r] = -m;
   // fragment addresses inside a 32-key half (byte offsets; the half adds 4096, the stage buffer its base)
@@ -570,17 +276,19 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restri
     vaddr[1] = tr_row * 128 + 64 * (1 ^ b3) + inrow;
   }
 
-  auto half_block = [&](const unsigned char* kbuf, const unsigned char* vbuf, int half, int key0, bool tail, bool first = false) {
+  // one 32-key half: scores, softmax in place, P.V.  `tail`: keys past the end of the sequence are masked through the
+  // accumulator's initial value (last halves only).  `first`: no running max yet - straight to the exact path.
+  auto half_block = [&](const unsigned char* kbuf, const unsigned char* vbuf, int half, int key0, bool tail, bool first) {
     const unsigned char* kh = kbuf + half * 4096;
-    auto scores = [&](bool raw) {
+    auto scores = [&](bool raw) {          // raw: q.k only (exact path); otherwise q.k - m
       f32x16 s;
       if (tail) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          s[r] = (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? (((FLAGS & 16) && !raw) ? cm[r] : 0.f) : -INFINITY;
+          s[r] = (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? (raw ? 0.f : cm[r]) : -INFINITY;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(*reinterpret_cast<const V8*>(kh + kaddr[sl]), qf[sl], s);
-      } else if ((FLAGS & 16) && !raw) {
+      } else if (!raw) {
         s = mfma32x32x16(*reinterpret_cast<const V8*>(kh + kaddr[0]), qf[0], cm);
 #pragma unroll
         for (int sl = 1; sl < 4; ++sl) s = mfma32x32x16(*reinterpret_cast<const V8*>(kh + kaddr[sl]), qf[sl], s);
@@ -593,37 +301,37 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restri
       return s;
     };
     f32x16 s;
-    f32x2 acc0 = {0.f, 0.f};
-    bool exact = (FLAGS & 64) && first;   // FLAGS & 64: the first half of a pass has no running max yet - no speculative try
+    f32x2_t acc0 = {0.f, 0.f};
+    bool exact = first;
     if (!exact) {
       s = scores(false);
-      if ((FLAGS & 48) == 48 && !tail) acc0 = exp_rowsum_ordered(s); else if (FLAGS & 16) acc0 = exp_rowsum(s); else acc0 = diet_softmax(s, c, mc);
+      acc0 = tail ? exp_rowsum(s) : exp_rowsum_ordered(s);
+      // every p <= 2^6 is implied by both partial sums <= 2^6; inf / NaN fail the test too
       exact = __builtin_amdgcn_ballot_w64(!(acc0[0] <= 64.0f && acc0[1] <= 64.0f)) != 0;
     }
-    if (exact) {   // wave-uniform, rare
+    if (exact) {                           // wave-uniform; first half of a pass, or a row maximum that grew by > 2^6
       s = scores(true);
       float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
       mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])),
                            fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
       mx = half_pair_max(mx);
       const float m_new = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);        // m = -1e30 initially -> alpha = 0
       m = m_new;
-      mc = m_new * c;
-      if (FLAGS & 16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cm[r] = -m_new;
-      }
+      for (int r = 0; r < 16; ++r) cm[r] = -m_new;
       l2 *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      acc0 = f32x2{0.f, 0.f};
+      float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -mc));
-        s[r + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], c, -mc));
-        acc0 += f32x2{s[r], s[r + 1]};
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_new);
+        a0 += s[r];
+        a1 += s[r + 1];
       }
+      acc0 = f32x2_t{a0, a1};
     }
     l2 += acc0;
     V8 pb0, pb1;
@@ -658,429 +366,62 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd5_kernel(const T* __restri
   };
   const int ns = (Tn + SK - 1) / SK, nfull = Tn / SK;
   int s = 0;
-  for (; s < nfull; ++s) {
+  for (; s < nfull; ++s) {                 // full stages: straight-line code, no per-half conditions
     stage_sync();
-    if (s + 1 < ns && !(FLAGS & 8) && !(FLAGS & 128)) issue(s + 1);
     const unsigned char* kb = &lds[s & 1][0][0];
     const unsigned char* vb = &lds[s & 1][1][0];
     if (active) half_block(kb, vb, 0, s * SK, false, s == 0);
-    if (s + 1 < ns && !(FLAGS & 8) && (FLAGS & 128)) issue(s + 1);   // FLAGS & 128: the DMA goes out between the halves
-    if (active) {
-#pragma unroll
-      for (int h = 1; h < NH; ++h) half_block(kb, vb, h, s * SK + 32 * h, false);
-    }
+    if (s + 1 < ns && !(FLAGS & 8)) issue(s + 1);
+    if (active) half_block(kb, vb, 1, s * SK + 32, false, false);
   }
-  if (s < ns) {                                                     // the ragged last stage: 1 .. SK-1 real keys
+  if (s < ns) {                            // the ragged last stage: 1 .. 63 real keys
     stage_sync();
     if (active) {
       const unsigned char* kb = &lds[s & 1][0][0];
       const unsigned char* vb = &lds[s & 1][1][0];
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int key0 = s * SK + 32 * h;
-        if (key0 < Tn) half_block(kb, vb, h, key0, key0 + 32 > Tn);
-      }
+      const int key0 = s * SK;
+      half_block(kb, vb, 0, key0, key0 + 32 > Tn, s == 0);
+      if (key0 + 32 < Tn) half_block(kb, vb, 1, key0 + 32, true, false);
     }
   }
-  float l = l2[0] + l2[1];
+  const float l = l2[0] + l2[1];
   DSS_CLOCK_END
 
   const float lsum = half_pair_sum(l);                  // the two half-waves hold disjoint keys of each query
   const float inv = 1.0f / lsum;
-  if (FLAGS & 1) {
-    // O^T -> full 128-byte rows: the wave's 32 x 64 output tile goes through a private 4 KB LDS patch (16-byte slot p
-    // of row r at slot p ^ ((r >> 1) & 7)), then 8 lanes store one row: 4 stores of 16 B per lane instead of 8 of 8 B,
-    // every store instruction writes 8 complete lines.
-    __builtin_amdgcn_s_barrier();                       // every wave is done with the last stage buffer
-    asm volatile("" ::: "memory");
-    unsigned char* patch = &lds[0][0][0] + wave * 4096;
-    if (active) {
-      const unsigned xs = (unsigned)(((li >> 1) & 7) << 4);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        V4 a, cc;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = from_f32<T>(o0[4 * g + i] * inv);
-          cc[i] = from_f32<T>(o1[4 * g + i] * inv);
-        }
-        *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(16 * g)) ^ xs) + 8 * hh) = a;
-        *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(64 + 16 * g)) ^ xs) + 8 * hh) = cc;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int rq = lane >> 3, pq = lane & 7;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = rq + 8 * i, q = q0 + row;
-        const V8 v = *reinterpret_cast<const V8*>(patch + row * 128 + 16 * (pq ^ ((row >> 1) & 7)));
-        V8* dst = reinterpret_cast<V8*>(out + ((long)b * Tn + q) * heads * DH + (long)head * DH + 8 * pq);
-        if (q < Tn) { if (FLAGS & 2) __builtin_nontemporal_store(v, dst); else *dst = v; }
-      }
-    }
-    return;
-  }
+  // O^T -> full 128-byte rows: the wave's 32 x 64 output tile goes through a private 4 KB LDS patch (16-byte slot p of
+  // row r at slot p ^ ((r >> 1) & 7): writes 2-way, reads conflict-free), then 8 lanes store one row.
+  __builtin_amdgcn_s_barrier();                         // every wave is done with the last stage buffers
+  asm volatile("" ::: "memory");
   if (!active) return;
-  const int q = q0 + li;
-  if (q < Tn) {
-    T* orow = out + ((long)b * Tn + q) * heads * DH + (long)head * DH;
+  unsigned char* patch = &lds[0][0][0] + wave * 4096;
+  const unsigned xs = (unsigned)(((li >> 1) & 7) << 4);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      V4 a, cc;
+  for (int g = 0; g < 4; ++g) {
+    V4 a, cc;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = from_f32<T>(o0[4 * g + i] * inv);
-        cc[i] = from_f32<T>(o1[4 * g + i] * inv);
-      }
-      *reinterpret_cast<V4*>(orow + 8 * g + 4 * hh) = a;
-      *reinterpret_cast<V4*>(orow + 32 + 8 * g + 4 * hh) = cc;
+    for (int i = 0; i < 4; ++i) {
+      a[i] = from_f32<T>(o0[4 * g + i] * inv);
+      cc[i] = from_f32<T>(o1[4 * g + i] * inv);
     }
+    *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(16 * g)) ^ xs) + 8 * hh) = a;
+    *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(64 + 16 * g)) ^ xs) + 8 * hh) = cc;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read of other lanes' data
+  const int rq = lane >> 3, pq = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rq + 8 * i, q = q0 + row;
+    const V8 v = *reinterpret_cast<const V8*>(patch + row * 128 + 16 * (pq ^ ((row >> 1) & 7)));
+    if (q < Tn) *reinterpret_cast<V8*>(out + ((long)b * Tn + q) * heads * DH + (long)head * DH + 8 * pq) = v;
   }
 }
 
-template <class T, int SK, int FLAGS, int NW = 8>
-static void launch_attention5(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
-                              int planar) {
-  const int nqb = ceil_div(Tn, 32 * NW);
-  hipLaunchKernelGGL((attn_fwd5_kernel<T, SK, FLAGS, NW>), dim3((unsigned)(nqb * heads * B)), dim3(64 * NW), 0, s,
-                     (const T*)qkv, (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
-}
-
-
-// ================================================================================================
-// attn_fwd6: attn_fwd5's stage pipeline (64-key stages by LDS-DMA, identical arithmetic) as a PERSISTENT grid.
-// What the lab measured on the bench shape (scripts/probes/attn_lab.hip, 290 x 901 x 6): with LDS reads, restaging and
-// barriers all ablated the kernel still needs 383-396 us of 518-531 - and removing nothing but the output stores saves
-// 55 us: a workgroup's slot is not released before its last stores have drained, the successor then starts with a
-// cold prologue (Q, first K/V stage, first barrier), and two slots per CU are too few to hide that.  Here a workgroup
-// keeps its slot and walks work items (one (image, head) x 256 queries each):
-//   * items come from per-XCD ticket counters (`tickets`, 8 x 64 B, zeroed by the launcher on the stream): the
-//     q-blocks of one (image, head) are consecutive tickets of ONE XCD's queue, so they run on that XCD close in time
-//     and its L2 serves K/V to all of them (as the block order of attn_fwd4/5 did); a workgroup whose home queue is
-//     empty moves on to the next XCD's.  Placement is a speed heuristic only - any workgroup may run any item.
-//   * the K/V stage stream is CONTINUOUS across items: during the last stage of item i the DMA of stage 0 of item
-//     i + 1 is already in flight; the ticket of item i + 1 was drawn during stage 0 of item i (wave 0, result picked
-//     up one stage later, handed to the other waves through LDS behind the stage barriers: needs >= 3 stages per item);
-//   * the next item's Q fragments are loaded right after the last P.V, into registers that are dead by then, and the
-//     output leaves as full 128-byte rows (private 4 KB LDS patch per wave) whose acknowledgements overlap the next
-//     item: the first stage wait of an item is s_waitcnt vmcnt(<row stores issued>), in-order retirement covers the
-//     older DMA pieces and Q loads without waiting for the stores.
-template <class T, int FLAGS>
-__global__ __launch_bounds__(512, 4) void attn_fwd6_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
-                                                           int heads, int nb, int nqb, float scale_log2, int planar,
-                                                           unsigned* __restrict__ tickets) {
-  typedef typename vec8<T>::type V8;
-  typedef typename vec4<T>::type V4;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr int SK = 64, NH = 2, OPB = SK * 128;
-  // one LDS object: [2 stage buffers][K | V][8 KB] = 32 KB, 8 x 4 KB output patches, 2 ticket slots
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * OPB + 8 * 4096 + 64];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, hh = lane >> 5;
-  const int groups = heads * nb;
-  const long plane = (long)nb * Tn * DH;
-  const long rs = planar ? DH : 3L * heads * DH;                    // row stride (halves)
-  const long koff = planar ? heads * plane : (long)heads * DH;      // q -> k ; q -> v is twice that
-  const unsigned rb = (unsigned)(rs * 2);
-  int* tick = reinterpret_cast<int*>(&lds[4 * OPB + 8 * 4096]);
-  unsigned char* patch = &lds[4 * OPB + wave * 4096];
-  const unsigned lds0 = (unsigned)(size_t)(lds_as3_t)(&lds[0]);
-  DSS_CLOCK_BEGIN
-
-  unsigned home;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home));
-  home &= 7u;
-  // queue x holds the (image, head) groups g = 8 j + x, nqb tickets each
-  auto queue_len = [&](unsigned x) { return (int)(((unsigned)groups + 7u - x) >> 3) * nqb; };
-  int qx = 0;                                                       // queues tried so far (wave 0 only)
-  auto draw_blocking = [&]() {                                      // wave 0: next item id = group << 8 | qblk, or -1
-    int item = -1;
-    while (qx < 8) {
-      const unsigned x = (home + (unsigned)qx) & 7u;
-      unsigned t = 0;
-      if (lane == 0) t = atomicAdd(&tickets[16 * x], 1u);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if ((int)t < queue_len(x)) { item = (int)(((8u * (t / (unsigned)nqb) + x) << 8) | (t % (unsigned)nqb)); break; }
-      ++qx;
-    }
-    return item;
-  };
-  auto base_of = [&](int item) {
-    const int group = item >> 8;
-    const int head = group % heads, b = group / heads;
-    return planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
-  };
-  auto uniform_ptr = [](const void* p) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
-  };
-  auto dma16 = [&](const unsigned char* src, unsigned off, unsigned dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(dst), "v"(off), "s"(src) : "memory");
-  };
-  // stage `s` of the item whose K rows start at kbase (uniform) into buffer `buf`; wave w moves piece w of K and of V
-  auto issue = [&](const unsigned char* kbase, int s, int buf) {
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));                                  // recomputed per stage: nothing hoisted, nothing spilled
-    const int r = 8 * wave + (lane >> 3);
-    int key = s * SK + r;
-    key = key < Tn ? key : Tn - 1;
-    const unsigned rowoff = (unsigned)key * rb;
-    const unsigned kc = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
-    const unsigned vc = (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2));
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * 2 * OPB + wave * 1024));
-    dma16(kbase, rowoff + 16u * kc, dst);
-    dma16(kbase + koff * 2, rowoff + 16u * vc, dst + OPB);
-  };
-  auto load_q = [&](V8* qf, const T* base, int q0) {
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));
-    const int li = lane & 31, hh = lane >> 5;
-    int qa = q0 + li;
-    qa = qa < Tn ? qa : Tn - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const V8*>(base + (long)qa * rs + 16 * s + 8 * hh);
-  };
-
-  // ---- first item ---------------------------------------------------------------------------------------------------
-  if (wave == 0) {
-    const int it = draw_blocking();
-    if (lane == 0) tick[0] = it;
-  }
-  __syncthreads();
-  int item = __builtin_amdgcn_readfirstlane(tick[0]);
-  if (item < 0) return;
-  const T* base = base_of(item);
-  const unsigned char* kbase = uniform_ptr(base + koff);
-  issue(kbase, 0, 0);
-  V8 qf[4];
-  load_q(qf, base, (item & 255) * 256 + wave * 32);
-  asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));   // hipcc waits for Q here, not inside the loop
-
-  const float c = scale_log2;
-  unsigned kaddr[4];
-  {
-    const unsigned xk = (unsigned)(((li >> 1) & 7) << 4);
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) kaddr[sl] = (unsigned)(li * 128) + (((unsigned)(32 * sl + 16 * hh)) ^ xk);
-  }
-  unsigned vaddr[2];
-  {
-    const unsigned tr_row = (unsigned)(4 * hh + ((lane & 15) >> 2));
-    const unsigned b3 = (unsigned)((lane >> 3) & 1);
-    const unsigned inrow = (unsigned)(32 * ((lane >> 4) & 1) + 8 * (lane & 3));
-    vaddr[0] = tr_row * 128 + 64 * (0 ^ b3) + inrow;
-    vaddr[1] = tr_row * 128 + 64 * (1 ^ b3) + inrow;
-  }
-  f32x16 o0, o1;
-  float m, mc;
-  f32x2 l2;
-
-  V8 abl_k, abl_v;                                            // lab ablation (FLAGS & 2): fragments read once
-  auto half_block = [&](const unsigned char* kbuf, const unsigned char* vbuf, int half, int key0, bool tail) {
-    const unsigned char* kh = kbuf + half * 4096;
-    auto kfrag = [&](int sl) { return (FLAGS & 2) ? abl_k : *reinterpret_cast<const V8*>(kh + kaddr[sl]); };
-    auto scores = [&]() {
-      f32x16 s;
-      if (tail) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? 0.f : -INFINITY;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(kfrag(sl), qf[sl], s);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(kfrag(sl), qf[sl], s);
-      }
-      return s;
-    };
-    f32x16 s = scores();
-    f32x2 acc0 = diet_softmax(s, c, mc);
-    if (__builtin_amdgcn_ballot_w64(!(acc0[0] <= 64.0f && acc0[1] <= 64.0f)) != 0) {   // wave-uniform, rare
-      s = scores();
-      float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])),
-                           fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
-      mx = half_pair_max(mx);
-      const float m_new = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-      m = m_new;
-      mc = m_new * c;
-      l2 *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      acc0 = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -mc));
-        s[r + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], c, -mc));
-        acc0 += f32x2{s[r], s[r + 1]};
-      }
-    }
-    l2 += acc0;
-    V8 pb0, pb1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pb0[e] = from_f32<T>(s[e]);
-      pb1[e] = from_f32<T>(s[8 + e]);
-    }
-    const unsigned char* vh = vbuf + half * 4096;
-    if (FLAGS & 2) {
-      o0 = mfma32x32x16(abl_v, pb0, o0);
-      o1 = mfma32x32x16(abl_v, pb0, o1);
-      o0 = mfma32x32x16(abl_v, pb1, o0);
-      o1 = mfma32x32x16(abl_v, pb1, o1);
-      return;
-    }
-    {
-      const V8 v0 = lds_read_tr_pair<T>(reinterpret_cast<const T*>(vh + vaddr[0]),
-                                        reinterpret_cast<const T*>(vh + vaddr[0] + 1024));
-      const V8 v1 = lds_read_tr_pair<T>(reinterpret_cast<const T*>(vh + vaddr[1]),
-                                        reinterpret_cast<const T*>(vh + vaddr[1] + 1024));
-      o0 = mfma32x32x16(v0, pb0, o0);
-      o1 = mfma32x32x16(v1, pb0, o1);
-    }
-    {
-      const V8 v0 = lds_read_tr_pair<T>(reinterpret_cast<const T*>(vh + vaddr[0] + 2048),
-                                        reinterpret_cast<const T*>(vh + vaddr[0] + 3072));
-      const V8 v1 = lds_read_tr_pair<T>(reinterpret_cast<const T*>(vh + vaddr[1] + 2048),
-                                        reinterpret_cast<const T*>(vh + vaddr[1] + 3072));
-      o0 = mfma32x32x16(v0, pb1, o0);
-      o1 = mfma32x32x16(v1, pb1, o1);
-    }
-  };
-
-  if (FLAGS & 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    abl_k = *reinterpret_cast<const V8*>(&lds[kaddr[0]]);
-    abl_v = lds_read_tr_pair<T>(reinterpret_cast<const T*>(&lds[OPB + vaddr[0]]), reinterpret_cast<const T*>(&lds[OPB + vaddr[0] + 1024]));
-  }
-  const int ns = (Tn + SK - 1) / SK, nfull = Tn / SK;      // ns >= 3 (launcher)
-  int gs = 0;                                               // global stage counter: buffer = gs & 1
-  int nstores = 0;                                          // row stores of the previous item still in flight (this wave)
-  for (;;) {
-    const int qblk = item & 255;
-    const int q0 = qblk * 256 + wave * 32;
-    const bool active = q0 < Tn;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    m = -1.0e30f; mc = -1.0e30f * scale_log2;
-    l2 = f32x2{0.f, 0.f};
-    int next = -1;
-    unsigned traw = 0;
-    const T* nbase = base;
-    // stage top: wait for the stage's data, ticket hand-over, barrier, next stage's DMA
-    auto stage_top = [&](int s) {
-      // own DMA pieces of this stage (and, at s = 0, the Q loads) have landed; the previous item's row stores may still fly
-      if (s == 0 && nstores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (s == 1 && wave == 0) {                            // ticket drawn during stage 0: resolve, publish in slot (gs & 1)
-        int it = -1;
-        const unsigned x = (home + (unsigned)qx) & 7u;
-        const unsigned t = __builtin_amdgcn_readfirstlane(traw);
-        if ((int)t < queue_len(x)) it = (int)(((8u * (t / (unsigned)nqb) + x) << 8) | (t % (unsigned)nqb));
-        else { ++qx; it = draw_blocking(); }
-        if (lane == 0) tick[gs & 1] = it;
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (s == 0 && wave == 0 && qx < 8) {                  // draw the next ticket; the result is looked at a stage later
-        if (lane == 0) traw = atomicAdd(&tickets[16 * ((home + (unsigned)qx) & 7u)], 1u);
-      }
-      if (s + 1 < ns) {
-        if (!(FLAGS & 1)) issue(kbase, s + 1, (gs + 1) & 1);
-      } else {                                              // last stage: the next item's first stage goes out now
-        // slot written at stage 1 (index (gs - (ns - 2)) & 1), at least one barrier ago
-        next = __builtin_amdgcn_readfirstlane(tick[(gs - (ns - 2)) & 1]);
-        if (next >= 0) {
-          nbase = base_of(next);
-          if (!(FLAGS & 1)) issue(uniform_ptr(nbase + koff), 0, (gs + 1) & 1);
-        }
-      }
-    };
-    int s = 0;
-    for (; s < nfull; ++s, ++gs) {
-      stage_top(s);
-      if (active) {
-        const unsigned char* kb = &lds[(gs & 1) * 2 * OPB];
-        half_block(kb, kb + OPB, 0, s * SK, false);
-        half_block(kb, kb + OPB, 1, s * SK + 32, false);
-      }
-    }
-    if (s < ns) {                                           // the ragged last stage: 1 .. 63 real keys
-      stage_top(s);
-      if (active) {
-        const unsigned char* kb = &lds[(gs & 1) * 2 * OPB];
-        const int key0 = s * SK;
-        half_block(kb, kb + OPB, 0, key0, key0 + 32 > Tn);
-        if (key0 + 32 < Tn) half_block(kb, kb + OPB, 1, key0 + 32, true);
-      }
-      ++gs;
-    }
-    // ---- item done: next Q into the registers that just died, then this item's output ------------------------------
-    const float l = l2[0] + l2[1];
-    const float lsum = half_pair_sum(l);
-    const float inv = 1.0f / lsum;
-    if (next >= 0) load_q(qf, nbase, (next & 255) * 256 + wave * 32);   // qf died with the last score MFMA
-    nstores = 0;
-    if (FLAGS & 4) {
-      asm volatile("" :: "v"(o0[0] * inv), "v"(o1[0]));
-    } else if (active) {
-      int lane = tid & 63;
-      asm volatile("" : "+v"(lane));                        // epilogue addressing recomputed per item (see issue())
-      const int li = lane & 31, hh = lane >> 5;
-      const int group = item >> 8;
-      const int head = group % heads, b = group / heads;
-      const unsigned xs = (unsigned)(((li >> 1) & 7) << 4);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        V4 a, cc;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = from_f32<T>(o0[4 * g + i] * inv);
-          cc[i] = from_f32<T>(o1[4 * g + i] * inv);
-        }
-        *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(16 * g)) ^ xs) + 8 * hh) = a;
-        *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(64 + 16 * g)) ^ xs) + 8 * hh) = cc;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int rq = lane >> 3, pq = lane & 7;
-      const bool all_rows = q0 + 32 <= Tn;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = rq + 8 * i, q = q0 + row;
-        const V8 v = *reinterpret_cast<const V8*>(patch + row * 128 + 16 * (pq ^ ((row >> 1) & 7)));
-        if (all_rows || q < Tn) *reinterpret_cast<V8*>(out + ((long)b * Tn + q) * heads * DH + (long)head * DH + 8 * pq) = v;
-      }
-      nstores = all_rows ? 4 : -1;                          // ragged wave: unknown count, wait for everything
-    }
-    if (next < 0) break;
-    item = next;
-    base = nbase;
-    kbase = uniform_ptr(base + koff);
-  }
-  DSS_CLOCK_END
-}
-
-template <class T, int FLAGS>
-static void launch_attention6(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
-                              int planar, unsigned* tickets, int nwg) {
-  const int nqb = ceil_div(Tn, 256);
-  (void)hipMemsetAsync(tickets, 0, 8 * 64, s);
-  hipLaunchKernelGGL((attn_fwd6_kernel<T, FLAGS>), dim3((unsigned)nwg), dim3(512), 0, s, (const T*)qkv, (T*)out, Tn,
-                     heads, B, nqb, scale * 1.4426950408889634f, planar, tickets);
-}
-
-template <class T>
+template <class T, int FLAGS = 0>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
                              int planar) {
   const int nqb = ceil_div(Tn, 256);
-  hipLaunchKernelGGL((attn_fwd4_kernel<T>), dim3((unsigned)(nqb * heads * B)), dim3(512), 0, s, (const T*)qkv,
+  hipLaunchKernelGGL((attn_fwd_kernel<T, FLAGS>), dim3((unsigned)(nqb * heads * B)), dim3(512), 0, s, (const T*)qkv,
                      (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
 }
 
@@ -1093,6 +434,9 @@ extern "C" int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int
               "dss_attention_fwd: qkv_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", qkv_layout);
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
   DSS_REQUIRE((long)B * heads * dss::ceil_div(T, 256) < 2147483647L, "dss_attention_fwd: too many workgroups");
+  // the DMA addresses rows with 32-bit byte offsets from the (image, head) base
+  DSS_REQUIRE((long)T * (qkv_layout == DSS_PLANAR64 ? 128L : 384L * heads) < 4294967296L,
+              "dss_attention_fwd: T=%d x heads=%d exceeds the 32-bit row offsets of the K/V stage DMA", T, heads);
   hipStream_t s = (hipStream_t)stream;
   const int planar = qkv_layout == DSS_PLANAR64;
   switch (dtype) {

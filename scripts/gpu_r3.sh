@@ -14,15 +14,9 @@ pmc_pass() {   # pmc_pass <tag> <counters...> -- <command...>
 }
 for STAGE in "$@"; do
   case $STAGE in
-    lab)   # attention variants A/B on the bench shapes
-      for ARGS in "290 901 6 1" "255 1024 6 1" "16 3601 12 0"; do
-        timeout 300 scripts/probes/attn_lab $ARGS -1 5 >> gpurun_out/attn_lab.log 2>&1; echo "lab($ARGS) exit $?"
-        [ -x scripts/probes/attn_lab_scalar ] && { echo "--- scalar softmax build (-fno-slp-vectorize)" >> gpurun_out/attn_lab.log; timeout 300 scripts/probes/attn_lab_scalar $ARGS -1 5 >> gpurun_out/attn_lab.log 2>&1; echo "lab_scalar($ARGS) exit $?"; }
-      done
-      cat gpurun_out/attn_lab.log;;
     lab1)   # main shape only, both builds; LAB_ONLY=<variant> restricts
       rm -f gpurun_out/attn_lab1.log
-      for BIN in attn_lab attn_lab_scalar; do
+      for BIN in attn_lab; do
         echo "--- $BIN" >> gpurun_out/attn_lab1.log
         timeout 120 scripts/probes/$BIN ${LAB_SHAPE:-290 901 6 1} ${LAB_ONLY:--1} 5 2>&1 | grep -v "ablation / not expected" >> gpurun_out/attn_lab1.log; echo "$BIN exit $?"
       done

@@ -1,6 +1,7 @@
-// attn_lab.hip - A/B bench of attention kernel variants on the bench shapes (random data), interleaved rounds in ONE process,
-// every variant checked against the product kernel (bitwise where the arithmetic is the same) and one image against an fp64
-// host reference.  Build (scripts/gpu_r3.sh lab):
+// attn_lab.hip - A/B bench of the attention kernel and its ablation switches on the bench shapes (random data), interleaved
+// rounds in ONE process; the product kernel is checked against an fp64 host reference on one image.  (Round 3's candidates -
+// the round-2 kernel, 128-key stages, four-wave workgroups, a persistent grid, packed / scalar / log2-domain softmax - were
+// compared with this harness before the losers were deleted: profiles/r03_attention_lab.txt.)  Build (scripts/gpu_r3.sh lab):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-honor-nans -mno-amdgpu-ieee scripts/probes/attn_lab.hip \
 //         deep-spectral-segmentation_amd/csrc/lib.hip -o scripts/probes/attn_lab
 // Run:   attn_lab [B T H planar [only-variant]]
@@ -16,48 +17,12 @@
 #include <vector>
 
 typedef void (*launch_fn)(const void*, void*, int, int, int, float, hipStream_t, int);
-template <int ABL>
-static void launch4(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s, int planar) {
-  const int nqb = dss::ceil_div(Tn, 256);
-  hipLaunchKernelGGL((dss::attn_fwd4_kernel<dss::f16, ABL>), dim3((unsigned)(nqb * heads * B)), dim3(512), 0, s,
-                     (const dss::f16*)qkv, (dss::f16*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
-}
-static unsigned* g_tickets = nullptr;
-static int g_nwg = 512;
-template <int FLAGS>
-static void launch6(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s, int planar) {
-  dss::launch_attention6<dss::f16, FLAGS>(qkv, out, B, Tn, heads, scale, s, planar, g_tickets, g_nwg);
-}
 struct Variant { const char* name; launch_fn fn; bool exact; };
 static const Variant VARIANTS[] = {
-    {"fwd4 (product r2)", launch4<0>, true},
-    {"fwd4 no-restage/no-barrier", launch4<1>, false},
-    {"fwd4 frags-in-regs", launch4<2>, false},
-    {"fwd4 no-restage+frags-in-regs", launch4<3>, false},
-    {"fwd4 all-ablated+no-store", launch4<7>, false},
-    {"fwd4 no-store", launch4<4>, false},
-    {"fwd5 SK64", dss::launch_attention5<dss::f16, 64, 0>, true},
-    {"fwd5 SK128", dss::launch_attention5<dss::f16, 128, 0>, true},
-    {"fwd5 SK64 rowstore", dss::launch_attention5<dss::f16, 64, 1>, true},
-    {"fwd5 SK128 rowstore", dss::launch_attention5<dss::f16, 128, 1>, true},
-    {"fwd6 persistent", launch6<0>, true},
-    {"fwd6 NO DMA", launch6<1>, false},
-    {"fwd6 frags-in-regs", launch6<2>, false},
-    {"fwd6 NO DMA+frags-in-regs", launch6<3>, false},
-    {"fwd6 all-ablated+no-store", launch6<7>, false},
-    {"fwd6 no-store", launch6<4>, false},
-    {"fwd5 SK64 rowstore log2Q ordered", dss::launch_attention5<dss::f16, 64, 49>, false},
-    {"fwd5 SK64 rs log2Q ord first-exact", dss::launch_attention5<dss::f16, 64, 49 + 64>, false},
-    {"fwd5 SK64 rs log2Q ord dma-mid", dss::launch_attention5<dss::f16, 64, 49 + 128>, false},
-    {"fwd5 SK64 rs log2Q ord first-exact dma-mid", dss::launch_attention5<dss::f16, 64, 49 + 192>, false},
-    {"fwd5 SK128 rs log2Q ord first-exact", dss::launch_attention5<dss::f16, 128, 49 + 64>, false},
-    {"fwd5 SK64 rowstore log2Q ordered NO BARRIER NO DMA", dss::launch_attention5<dss::f16, 64, 61>, false},
-    {"fwd5 SK64 rowstore log2Q", dss::launch_attention5<dss::f16, 64, 17>, false},
-    {"fwd5 SK128 rowstore log2Q", dss::launch_attention5<dss::f16, 128, 17>, false},
-    {"fwd5 SK64 rowstore log2Q NO BARRIER NO DMA", dss::launch_attention5<dss::f16, 64, 29>, false},
-    {"fwd5 SK64 rowstore NO BARRIER", dss::launch_attention5<dss::f16, 64, 5>, false},
-    {"fwd5 SK64 rowstore NO DMA", dss::launch_attention5<dss::f16, 64, 9>, false},
-    {"fwd5 SK64 rowstore NO BARRIER NO DMA", dss::launch_attention5<dss::f16, 64, 13>, false},
+    {"attn_fwd (product)", dss::launch_attention<dss::f16, 0>, true},
+    {"attn_fwd NO BARRIER", dss::launch_attention<dss::f16, 4>, false},
+    {"attn_fwd NO DMA", dss::launch_attention<dss::f16, 8>, false},
+    {"attn_fwd NO BARRIER NO DMA", dss::launch_attention<dss::f16, 12>, false},
 };
 static const int NV = sizeof(VARIANTS) / sizeof(VARIANTS[0]);
 
@@ -85,8 +50,6 @@ int main(int argc, char** argv) {
   if (hipMalloc(&qkv, n * 2) != hipSuccess || hipMalloc(&out, nout * 2) != hipSuccess ||
       hipMalloc(&ref, nout * 2) != hipSuccess) return 1;
   (void)hipMemcpy(qkv, h.data(), n * 2, hipMemcpyHostToDevice);
-  if (hipMalloc(&g_tickets, 8 * 64) != hipSuccess) return 1;
-  if (getenv("LAB_NWG")) g_nwg = atoi(getenv("LAB_NWG"));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const double flops = 4.0 * T * (double)T * H * 64 * B;
