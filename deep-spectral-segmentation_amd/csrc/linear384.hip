@@ -105,7 +105,9 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
   // chunks, whose arrival is awaited explicitly (wait_dma) by the issuing waves.
   auto phase_barrier = [&]() {
     asm volatile("" ::: "memory");
+#ifndef DSS_LINEAR_NO_BARRIER   // lab ablation (scripts/gpu_r3.sh linear_nobar): waves drift freely, results wrong
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   };
   // vmcnt retires in issue order (gfx9: loads, LDS-DMA and stores share it): with the 8 tile stores of an odd chunk
