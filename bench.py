@@ -70,7 +70,15 @@ def parse():
                     help="N=1 only: after the main measurement, time this many steps with the OTHER --w-dtype and report "
                          "them as value_w_<dtype> (0 = skip)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images of the same workload timed on the CPU oracle")
-    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images generated per rank")
+    ap.add_argument("--parity-images", type=int, default=32,
+                    help="images whose GPU eigenvectors are checked against the CPU oracle (the first --cpu-images of them "
+                         "are the timed CPU baseline; 0 = only those)")
+    ap.add_argument("--distinct", type=int, default=1000,
+                    help="distinct synthetic images generated per rank (BASELINE.json configs[1]: 1k synthetic images)")
+    ap.add_argument("--dino-like-steps", type=int, default=1,
+                    help="N=1 only: after the main measurement, time this many steps with synthetic.dino_like_state_dict "
+                         "weights (outlier channels, sharp logits: the spectrum a trained DINO produces is harder for the "
+                         "eigensolver than random-weight features) and report value_dino_like_weights + its passes per image")
     ap.add_argument("--resident", action="store_true",
                     help="diagnostic: keep the images resident in HBM (no H2D in the timed region; NOT the reported mode)")
     ap.add_argument("--min-warmup-seconds", type=float, default=4.0,
@@ -103,6 +111,22 @@ def spawn_ranks_if_needed(a):
     print(f"[bench] --gpus {a.gpus} without a launcher: spawning {a.gpus} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.execv(sys.executable, cmd)
+
+
+def baseline_config_name(a, world):
+    """Which entry of BASELINE.json `configs` this run's workload is (the line must not claim another one's)."""
+    if a.model == "dino_vits16" and a.size == 480 and a.K == 5:
+        if a.dataset == 10000:
+            return "BASELINE.json configs[3]" + ("" if world == 8 else f", its {world}-GPU leg")
+        if a.dataset == 0:
+            return "BASELINE.json configs[1]" if world == 1 else f"BASELINE.json configs[1] per GPU, {world} GPUs weak-scaled"
+    if a.model == "dino_vitb8" and a.size == 480 and a.K == 15 and a.dataset == 0:
+        return "BASELINE.json configs[2]" if world == 1 else f"BASELINE.json configs[2] per GPU, {world} GPUs weak-scaled"
+    if a.model == "dino_vits16" and a.size == 224 and a.K == 5:
+        return "the shape of BASELINE.json configs[0] (its 16-image CPU run is the cpu_baseline leg's territory)"
+    if a.model == "dino_vitb8" and a.K == 20:
+        return "BASELINE.json configs[4] at ONE image size (the mixed 320-640 px set runs through the CLI tests)"
+    return "not a BASELINE.json config"
 
 
 _OVERLAP = {}
@@ -248,7 +272,7 @@ def pmc_traffic(kernel, a):
     return best
 
 
-def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol):
+def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol, n_parity=0):
     """The oracle (CPU restatement of the reference path) on the same synthetic images/weights, all host
     cores; also yields the eigenvector parity of the GPU results on those images: the rule of tests/util.check_eigs
     (isolated eigenvalues: 1 - |cos| per vector; eigenvalues closer than 1e-4: D-weighted principal angle of the
@@ -258,17 +282,20 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol)
 
     ref = vit_ref.build_ref_vit(model_name, sd)
     cores = torch.get_num_threads()
-    times, worst_vec, worst_cluster, ok, clusters = [], 0.0, 0.0, True, []
-    for i in range(n_images + 1):  # image 0 is the warm-up
+    times, worst_vec, worst_cluster, ok, clusters, draws = [], 0.0, 0.0, True, [], []
+    n_total = max(n_images + 1, n_parity)
+    for i in range(n_total):  # image 0 is the warm-up of the timed baseline
         img = synthetic.synthetic_image(i, size, size)
         t0 = time.perf_counter()
         k = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
-        lam, vec = spectral_ref.ref_laplacian_eigs(k, K)   # the timed CPU path: exactly the reference's op sequence
-        dt = time.perf_counter() - t0
-        if i > 0:
-            times.append(dt)
+        if i <= n_images:
+            lam, vec = spectral_ref.ref_laplacian_eigs(k, K)   # the timed CPU path: exactly the reference's op sequence
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
         # untimed: a validated draw of the same call + fp64 extra pairs to decide clusters at the edge of the K wanted
-        lam, vec, ext, _ = spectral_ref.ref_laplacian_eigs_ext(k, K)
+        lam, vec, ext, ndraw = spectral_ref.ref_laplacian_eigs_ext(k, K)
+        draws.append(int(ndraw))
         report = []
         try:
             ce = check_eigs(gpu_vecs[i].cpu().numpy(), gpu_vals[i].cpu().numpy(), vec.numpy(), lam.numpy(),
@@ -278,7 +305,10 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol)
             ok = False
             print(f"[bench] parity failure: {e}", file=sys.stderr)
         worst_cluster = max([worst_cluster] + [c["err"] for c in report])
-        clusters.append([{**c, "err": float(f"{c['err']:.3g}"), "max_vector_cos_err": float(f"{c['max_vector_cos_err']:.3g}")}
+        lam_x = np.asarray(ext[0], np.float64)   # fp64 eigenvalues 0 .. K + E - 1 of the same problem
+        clusters.append([{**c, "err": float(f"{c['err']:.3g}"), "max_vector_cos_err": float(f"{c['max_vector_cos_err']:.3g}"),
+                          # how far the chained cluster reaches in eigenvalue (a tight pair vs a long chain of 1e-4 gaps)
+                          "cluster_span": float(f"{float(lam_x[min(c['last'], len(lam_x) - 1)] - lam_x[c['first']]):.3g}")}
                          for c in report if c["kind"] != "isolated"])
     return ({"value": round(len(times) / sum(times), 3), "unit": "images/s", "cores": cores, "kind": "port",
              "sample": f"{len(times)} of the same {size}x{size} synthetic images, torch-CPU fp32 ViT + "
@@ -286,7 +316,11 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol)
             {"rule": "tests/util.check_eigs: every cluster of eigenvalues (gaps < 1e-4) bounded by 1e-4; isolated -> "
                      "1-|cos| per vector, cluster -> D-weighted principal angle of the spans",
              "max_cluster_err_vs_cpu": worst_cluster, "max_vector_cos_err_vs_cpu": worst_vec,
-             "all_within_1e-4": ok, "eigenvalue_tol": lam_tol, "images": n_images + 1,
+             "all_within_1e-4": ok, "eigenvalue_tol": lam_tol, "images": n_total,
+             # reference draws per image (oracle/spectral_ref.ref_laplacian_eigs_ext): 1 = the reference's first ARPACK run
+             # was the target; k > 1 = k - 1 runs were > 1e-5 from fp64 and re-drawn; negative = every draw was bad and
+             # the fp64 solution itself is the target
+             "reference_draws": draws, "images_on_fp64_target": int(sum(1 for d_ in draws if d_ < 0)),
              "non_isolated_clusters_per_image": clusters})
 
 
@@ -381,8 +415,10 @@ def main():
 
     # synthetic images in PINNED HOST memory (rank r owns global indices r, r+world, ...)
     n_distinct = min(a.distinct, a.batch * (len(counts) + a.warmup))
-    host = torch.from_numpy(np.stack([synthetic.synthetic_image(rank + world * i, a.size, a.size)
-                                      for i in range(n_distinct)])).pin_memory()
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:   # numpy releases the GIL: ~40 ms/image serial
+        host = torch.from_numpy(np.stack(list(ex.map(lambda i: synthetic.synthetic_image(rank + world * i, a.size, a.size),
+                                                     range(n_distinct))))).pin_memory()
     feeder = ImageFeeder(host, a.batch, dev, resident=a.resident)
 
     from dss_amd.vit import setup_gemm_tuning
@@ -407,6 +443,15 @@ def main():
         distributed.gather_records_to_root(*distributed.pack_records(ids, warm[0], warm[1]))
         del ids
     del warm
+    torch.cuda.synchronize()
+
+    # what the HOST needs to enqueue one step (all launches of the ViT forwards + affinity + eigensolver) when the queue
+    # is empty and nothing blocks it: the ceiling the launch path alone would impose
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    step(model, feeder.get(n_warm - 1) if n_warm > 0 else host[: a.batch].to(dev), a.K, a.vit_batch, a.overlap,
+         a.vit_streams, a.w_dtype)
+    host_only_ms = (time.perf_counter() - t_h) * 1e3
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
@@ -442,9 +487,10 @@ def main():
             "scaling": "strong" if a.dataset > 0 else "weak",
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": f"{a.model} {a.size}x{a.size} K={a.K}, {a.batch} images/step/GPU, one B=1 result "
-                                   f"per image (BASELINE.json configs[1])" +
-                                   (f"; fixed set of {a.dataset} images round-robin over {world} GPU(s) "
-                                    f"(BASELINE.json configs[3])" if a.dataset > 0 else ""),
+                                   f"per image ({baseline_config_name(a, world)})" +
+                                   (f"; fixed set of {a.dataset} images round-robin over {world} GPU(s)"
+                                    if a.dataset > 0 else ""),
+                       "distinct_images": n_distinct,
                        "images_per_step": a.batch, "images_total": n_images,
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
                        "vit_operands": "f16" if dtype == torch.float16 else "bf16", "accumulate": "fp32",
@@ -459,7 +505,11 @@ def main():
                        "stage_overlap": a.overlap, "gelu": a.gelu},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
-            "host_enqueue_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
+            # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
+            # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
+            "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
+            # ... the CPU work alone: one full step enqueued on an EMPTY queue (no sync inside, timers off)
+            "host_enqueue_ms_per_step": round(host_only_ms, 3),
         }
     if world == 1 and a.companion_steps > 0 and a.dataset == 0:
         other = "f32" if a.w_dtype == "u16" else "u16"
@@ -470,11 +520,28 @@ def main():
         torch.cuda.synchronize()
         e2, _, _, _ = run_steps(model, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, other)
         out[f"value_w_{other}"] = round(a.companion_steps * a.batch / e2, 2)
+    if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
+        # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
+        # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
+        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu)
+        for i in range(2):
+            feeder.prefetch(i)
+            step(dl, feeder.get(i), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+            feeder.release(i)
+        torch.cuda.synchronize()
+        e3, _, inf3, _ = run_steps(dl, feeder, [a.batch] * a.dino_like_steps, a, rank, world, n_patches, a.w_dtype)
+        inf3 = torch.cat(inf3)
+        out["value_dino_like_weights"] = round(a.dino_like_steps * a.batch / e3, 2)
+        out["passes_per_image_dino_like_weights"] = round(float(inf3.abs().float().mean().item()), 2)
+        out["unconverged_images_dino_like_weights"] = int((inf3 <= 0).sum().item())
+        del dl
     if rank == 0:
         if world == 1 and a.cpu_images > 0:
-            first = step(model, host[: a.cpu_images + 1].to(dev), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+            n_par = max(a.cpu_images + 1, a.parity_images)
+            first = step(model, host[:n_par].to(dev), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a.model, sd, a.size, a.K, a.cpu_images, first[1], first[0],
-                                                              lam_tol=1e-3 if dtype == torch.float16 else 1e-2)
+                                                              lam_tol=1e-3 if dtype == torch.float16 else 1e-2,
+                                                              n_parity=a.parity_images)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

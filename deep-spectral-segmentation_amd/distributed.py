@@ -100,13 +100,16 @@ def gather_records_to_root(meta: torch.Tensor, payload: torch.Tensor):
         sizes = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         dist.gather(mine, sizes, dst=0)                                    # round 1: sizes
         if rank != 0:
-            ops = [dist.P2POp(dist.isend, meta.reshape(-1), 0), dist.P2POp(dist.isend, payload, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            if meta.shape[0] > 0:            # a rank with nothing to send posts nothing (rank 0 posts no receive for it)
+                ops = [dist.P2POp(dist.isend, meta.reshape(-1), 0), dist.P2POp(dist.isend, payload, 0)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
             return None
         metas, flats, ops = [meta], [payload], []
         for r in range(1, world):
             n_r, f_r = (int(v) for v in sizes[r].tolist())
+            if n_r == 0:                     # fewer items than ranks: no zero-byte point-to-point operations
+                continue
             metas.append(torch.empty((n_r, 3), dtype=torch.int64, device=dev))
             flats.append(torch.empty((f_r,), dtype=torch.float32, device=dev))
             ops += [dist.P2POp(dist.irecv, metas[-1].view(-1), r), dist.P2POp(dist.irecv, flats[-1], r)]
@@ -114,6 +117,8 @@ def gather_records_to_root(meta: torch.Tensor, payload: torch.Tensor):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         meta, payload = torch.cat(metas), torch.cat(flats)
+    if meta.shape[0] == 0:                   # nothing anywhere (an empty shard list): nothing to order
+        return meta, payload
     # order by item id: per-record offsets into the concatenated payload
     lens = meta[:, 1] * meta[:, 2] + meta[:, 2]
     offs = torch.cumsum(lens, 0) - lens

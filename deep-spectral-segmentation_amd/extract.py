@@ -212,7 +212,10 @@ def _load_feature_chunk(args):
     groups: Dict[Tuple[int, ...], Tuple[list, list]] = {}
     for f in files:
         data_dict, feats = _load_features(str(f), which_features)
-        meta = {k: v for k, v in data_dict.items() if not torch.is_tensor(v) or v.numel() <= 16}
+        # small tensors (the 0-d `indices`) travel as Python values: a tensor would cross the process boundary as its own
+        # shared-memory storage - one file descriptor per file, hundreds in flight with 32-file chunks
+        meta = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in data_dict.items()
+                if not torch.is_tensor(v) or v.numel() <= 16}
         metas, tensors = groups.setdefault(tuple(feats.shape), ([], []))
         metas.append(meta), tensors.append(feats)
     return [(metas, torch.stack(tensors)) for metas, tensors in groups.values()]
@@ -451,6 +454,17 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
     bad = (info <= 0).nonzero().flatten().tolist()
     if bad:
         print(f"[dss] WARNING: eigensolver did not converge for {[items[j][0] for j in bad]} (saved as is)")
+    # the eigen files first: whatever happens in the optional segmentation below, the batch's results are on their way
+    ev_h, vec_h = ev.cpu(), vec.cpu()
+    if saver is None:
+        for j, (output_file, _) in enumerate(items):
+            torch.save(*_build_eig_file((ev_h, vec_h), (j, output_file, problem)))
+    else:
+        saver.submit_batch("eigs", (ev_h, vec_h), [(j, output_file, problem) for j, (output_file, _) in enumerate(items)])
+    if segment is not None and segment["grid"][0] * segment["grid"][1] > 8192 and segment.get("multi_region_dir"):
+        print(f"[dss] WARNING: {segment['grid'][0]} x {segment['grid'][1]} points exceed the on-device K-means (8192): no "
+              f"multi-region PNGs for {[Path(o).stem for o, _ in items]}; run extract_multi_region_segmentations on the eigen files")
+        segment = {**segment, "multi_region_dir": None}
     if segment is not None:
         # the segmentations of extract.py:283-426 straight from the device-resident eigenvectors,
         # no .pth round trip (same algorithms on the device: threshold of the Fiedler vector; Lloyd K-means + border vote)
@@ -459,10 +473,16 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
         if segment.get("single_region_dir"):
             pngs.append((segment["single_region_dir"], spectral.single_region_masks(vec, segment["threshold"])))
         if segment.get("multi_region_dir"):
-            pngs.append((segment["multi_region_dir"], spectral.multi_region_segments(
-                ev, vec, (hp, wp), adaptive=segment["adaptive"], non_adaptive_num_segments=segment["num_segments"],
-                infer_bg_index=segment["infer_bg_index"], num_eigenvectors=segment["num_eigenvectors"],
-                seed=segment["seed"]).reshape(len(items), -1)))
+            # one launch per image, seeded from the image's own name: the k-means++ draw - hence the label numbering
+            # before the border vote - does not depend on batch size, shape bucket or rank count
+            import zlib
+            maps = [spectral.multi_region_segments(
+                ev[j:j + 1], vec[j:j + 1], (hp, wp), adaptive=segment["adaptive"],
+                non_adaptive_num_segments=segment["num_segments"], infer_bg_index=segment["infer_bg_index"],
+                num_eigenvectors=segment["num_eigenvectors"],
+                seed=(int(segment["seed"]) ^ zlib.crc32(Path(output_file).stem.encode())) & 0x7fffffff).reshape(1, -1)
+                for j, (output_file, _) in enumerate(items)]
+            pngs.append((segment["multi_region_dir"], torch.cat(maps)))
         for out_dir, maps in pngs:
             maps = maps.cpu()
             png_items = [(j, str(Path(out_dir) / f"{Path(output_file).stem}.png"), hp, wp)
@@ -472,12 +492,6 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
                     _write_png(*_build_png_file((maps,), it))
             else:
                 saver.submit_batch("png", (maps,), png_items)
-    ev, vec = ev.cpu(), vec.cpu()
-    if saver is None:
-        for j, (output_file, _) in enumerate(items):
-            torch.save(*_build_eig_file((ev, vec), (j, output_file, problem)))
-    else:
-        saver.submit_batch("eigs", (ev, vec), [(j, output_file, problem) for j, (output_file, _) in enumerate(items)])
 
 
 def _extract_eig(inp: Tuple[int, str], K: int, images_root: str, output_dir: str,
@@ -523,6 +537,14 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             if which_matrix not in ("laplacian", "matting_laplacian"):
                 raise ValueError("the on-device segmentations use eigenvector 1 of the Laplacian branches")
             Path(extra).mkdir(parents=True, exist_ok=True)
+    if multi_region_dir:
+        # limits of the on-device K-means (csrc/segment.hip: <= 32 clusters, <= 64 coordinates), checked before any work
+        dims = min(int(num_eigenvectors), int(K) - 1)
+        kmax = int(K) - 1 if adaptive else int(non_adaptive_num_segments)
+        if int(K) < 2 or dims < 1 or dims > 64 or kmax < 1 or kmax > 32:
+            raise ValueError(f"--multi_region_dir: the on-device K-means takes 1..64 eigenvector coordinates and 1..32 "
+                             f"segments (K={K}, num_eigenvectors={num_eigenvectors} -> {dims} coordinates, up to {kmax} "
+                             f"segments); lower them or run extract_multi_region_segmentations on the saved eigen files")
     kwargs = dict(K=K, which_matrix=which_matrix, which_features=which_features,
                   which_color_matrix=which_color_matrix, normalize=normalize, threshold_at_zero=threshold_at_zero,
                   images_root=images_root, output_dir=output_dir, image_downsample_factor=image_downsample_factor,

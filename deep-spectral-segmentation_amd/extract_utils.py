@@ -258,13 +258,20 @@ def knn_affinity(image: torch.Tensor, n_neighbors=(20, 10), distance_weights=(2.
     return out
 
 
+RW_EXPONENT = 900.0   # pymatting's `_rw_laplacian`: `wij = np.exp(-900 * np.linalg.norm(zi - zj) ** 2)` - a constant, not 1 / sigma^2
+
+
 @torch.no_grad()
 def rw_affinity(image: torch.Tensor, sigma: float = 0.033, radius: int = 1) -> torch.Tensor:
     """Random-walk colour affinity (reference extract_utils.py:192-204) on the GPU, dense ``[H W, H W]`` f32.
-    pymatting's ``_rw_laplacian`` is absent from this image and from /root/reference: restated from its documented
-    definition (Grady et al. 2005, eq. 4) - every pixel is linked to the ``(2 r + 1)^2`` window around it, coordinates
-    clamped to the image (so border pixels link to themselves / to a neighbour more than once and the duplicates add up),
-    with weight ``exp(-|I_i - I_j|^2 / sigma^2)``.  UNPINNED against pymatting itself."""
+    The arithmetic is pymatting's ``_rw_laplacian(image, sigma, radius)`` (third party, unpinned in the reference's
+    requirements, absent from this image): every pixel is linked to the ``(2 r + 1)^2`` window around it, coordinates
+    clamped to the image (so border pixels link to themselves / to a neighbour more than once and the duplicates add up -
+    the reference's ``csr_matrix((values, (i, j)))`` sums them), with weight ``exp(-900 |I_i - I_j|^2)``.  As published,
+    that function takes ``sigma`` (Grady et al. 2005, eq. 4 would give ``1 / sigma^2 = 918`` at the default 0.033) but
+    its body hard-codes the 900: ``sigma`` is accepted and unused, here as there.  Restated from the published source, not
+    executed: no pymatting run exists to pin it with."""
+    del sigma   # see above: the published implementation ignores it
     h, w = image.shape[:2]
     n = h * w
     dev = image.device
@@ -275,6 +282,6 @@ def rw_affinity(image: torch.Tensor, sigma: float = 0.033, radius: int = 1) -> t
     for dy in range(-radius, radius + 1):
         for dx in range(-radius, radius + 1):
             y2, x2 = (ys + dy).clamp(0, h - 1), (xs + dx).clamp(0, w - 1)
-            wij = torch.exp(-((img - img[y2, x2]) ** 2).sum(-1) / (sigma * sigma)).reshape(-1)
+            wij = torch.exp(-RW_EXPONENT * ((img - img[y2, x2]) ** 2).sum(-1)).reshape(-1)
             out.index_put_((i, (x2 + y2 * w).reshape(-1)), wij, accumulate=True)
     return out.to(torch.float32)

@@ -22,7 +22,11 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
     eigenvectors ``[B, K, N]``, info ``[B]``)."""
     k = model.extract_k(img_u8, which_block=which_block)
     # the features just came out of the half-precision ViT (relative error ~1e-3): the fused affinity build, which rounds
-    # them to f16 (2^-11) on its way into the MFMAs, costs nothing in accuracy here
+    # them to f16 (2^-11) on its way into the MFMAs, costs nothing in accuracy here.  Its own tolerance, for callers with
+    # EXACT fp32 features: |dW| <= 5e-5, eigenvalues within ~6e-5 of the fp32 build - looser than the 1e-5 eigenvalue bar
+    # `extract_eigs` holds on .pth features, which is why that command uses the 'split' build (DSS_AFFINITY=split here);
+    # end to end (f16 ViT + this build) the eigenvalues are within 1e-3, the eigenvectors within 1e-6 in cosine of the
+    # all-fp32 CPU path (bench.py `parity`, eigenvalue_tol 1e-3).
     ev, vec, info = spectral.laplacian_eigs_from_features(k, K, normalize=normalize,
                                                           threshold_at_zero=threshold_at_zero, strict=strict,
                                                           affinity_mode=os.environ.get("DSS_AFFINITY", "fused"))

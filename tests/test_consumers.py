@@ -228,7 +228,8 @@ def test_knn_affinity_matches_kdtree(hw, dev):
 
 @pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
 def test_rw_affinity_matches_pixel_loop(dev):
-    """Scalar restatement of the documented random-walk weights (window r = 1, clamped coordinates, duplicates add)."""
+    """Scalar restatement of pymatting's `_rw_laplacian` loop (window r = 1, clamped coordinates, duplicates add, the
+    hard-coded exp(-900 |dI|^2) - `sigma` is an unused argument there and here)."""
     dev = _device(dev)
     img = synthetic.synthetic_image(32, 9, 7).astype(np.float64) / 255.0
     h, w = img.shape[:2]
@@ -238,9 +239,10 @@ def test_rw_affinity_matches_pixel_loop(dev):
             for dy in (-1, 0, 1):
                 for dx in (-1, 0, 1):
                     y2, x2 = max(0, min(h - 1, y + dy)), max(0, min(w - 1, x + dx))
-                    want[x + y * w, x2 + y2 * w] += np.exp(-np.sum((img[y, x] - img[y2, x2]) ** 2) / 0.033 ** 2)
+                    want[x + y * w, x2 + y2 * w] += np.exp(-900 * np.linalg.norm(img[y, x] - img[y2, x2]) ** 2)
     got = extract_utils.rw_affinity(torch.from_numpy(img).to(dev)).cpu().numpy()
     assert np.allclose(got, want, rtol=1e-6, atol=1e-9) and np.allclose(got, got.T)
+    assert np.array_equal(got, extract_utils.rw_affinity(torch.from_numpy(img).to(dev), sigma=0.1).cpu().numpy())
 
 
 @pytest.mark.gpu

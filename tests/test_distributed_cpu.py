@@ -82,3 +82,76 @@ def test_shard_and_gather_world2():
         p.join(60)
         assert p.exitcode == 0
     assert ok
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# world 8 (BASELINE configs[3] / [4]: one node, eight ranks): uneven shards, mixed N / K, ranks with NOTHING to send
+def _worker8(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = distributed.shard_indices(total, rank, world)
+    assert mine == list(range(rank, total, world))
+    groups = {}
+    for i in mine:
+        groups.setdefault(_shape_of(i), []).append(i)
+    ids, evs, vcs = [], [], []
+    for (n, k), items in groups.items():
+        ids.append(torch.tensor([BIG_ID + i for i in items], dtype=torch.int64))
+        evs.append(torch.stack([_fake_result(i, n, k)[0] for i in items]))
+        vcs.append(torch.stack([_fake_result(i, n, k)[1] for i in items]))
+    if mine:
+        meta, payload = distributed.pack_records(ids, evs, vcs)
+    else:           # fewer items than ranks: this rank holds no record at all
+        meta, payload = torch.empty((0, 3), dtype=torch.int64), torch.empty((0,), dtype=torch.float32)
+    got = distributed.gather_records_to_root(meta, payload)
+    if rank == 0:
+        recs = distributed.unpack_records(*got)
+        ok = [r[0] for r in recs] == [BIG_ID + i for i in range(total)]
+        for i, (item, val, vec) in enumerate(recs):
+            n, k = _shape_of(i)
+            rv, re = _fake_result(i, n, k)
+            ok = ok and tuple(vec.shape) == (k, n) and torch.equal(val, rv) and torch.equal(vec, re)
+        q.put(ok)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world8(total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, total, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_shard_and_gather_world8_uneven_mixed_sizes():
+    """61 items over 8 ranks (shards of 8 and 7), two result shapes interleaved, int64 ids: every item once, in order."""
+    _run_world8(61)
+
+
+def test_gather_world8_with_empty_ranks():
+    """5 items over 8 ranks: three ranks have nothing to send - no zero-byte point-to-point operation is posted."""
+    _run_world8(5)
+
+
+def test_gather_single_process_and_empty():
+    """No process group: the gather is the identity (ordered by id); an empty record set stays empty."""
+    ids = torch.tensor([5, 2, 9], dtype=torch.int64)
+    ev = torch.stack([_fake_result(int(i))[0] for i in ids])
+    vc = torch.stack([_fake_result(int(i))[1] for i in ids])
+    meta, payload = distributed.gather_records_to_root(*distributed.pack_records(ids, ev, vc))
+    assert meta[:, 0].tolist() == [2, 5, 9]
+    for (item, val, vec) in distributed.unpack_records(meta, payload):
+        assert torch.equal(val, _fake_result(item)[0]) and torch.equal(vec, _fake_result(item)[1])
+    meta, payload = distributed.gather_records_to_root(torch.empty((0, 3), dtype=torch.int64), torch.empty((0,)))
+    assert meta.shape == (0, 3) and payload.numel() == 0

@@ -60,6 +60,53 @@ def test_patch_indexing_on_the_hip_path():
     assert set(moved) >= {r1 * wp + c1, r2 * wp + c2}
 
 
+def test_patch_indexing_exact_probe_on_the_hip_path(golden_dir):
+    """The index probe of tests/golden/index_probe.npz (the reference's own lines 96-98 driven by a model whose qkv
+    output ENCODES token and column: k[n][j] = 1000 * (n + 1) + (D + j)) reproduced through `DinoViT.extract_k` and every
+    kernel under it, EXACTLY.  A real-width model cannot carry the golden's 12-channel encoder, but it can carry the same
+    code with weights chosen so that nothing rounds:
+      * all weights zero except the last block's K rows; patch embedding zero, so the residual stream stays the injected
+        position rows through all eleven blocks (LayerNorm, qkv / proj / fc1 kernels, attention on all-zero q, k, v, the
+        library fc2 - every launch runs, every branch output is an exact 0);
+      * token t's row: +2^15 on channels {t % 64, 64 + t // 64, 128}, -2^15 on {381, 382, 383}: mean 0, variance 2^24,
+        so the last LayerNorm gives +-8 there and 0 elsewhere (fp32 last-bit differences vanish in the f16 operand);
+      * K rows: W[j][c] = 128 c (c < 64), 8192 (c - 64) (64 <= c < 68), 0 otherwise - all exact in f16 - bias D + j:
+        k[n][j] = 8 * (128 (t % 64) + 8192 (t // 64)) + D + j = 1024 t + D + j with t = n + 1, summed exactly in fp32.
+    The same image as the golden (50 x 70: 3 x 4 patches after the crop), the same decoded (token, column) table."""
+    g = np.load(golden_dir / "index_probe.npz")
+    gd, gh, gw, gp = int(g["heads"]) * int(g["dh"]), int(g["h"]), int(g["w"]), int(g["patch"])
+    d = 384
+    sd = {k: torch.zeros_like(v) for k, v in synthetic.synthetic_state_dict("dino_vits16", 0).items()}
+    for i in range(12):
+        sd[f"blocks.{i}.norm1.weight"].fill_(1.0)
+        sd[f"blocks.{i}.norm2.weight"].fill_(1.0)
+    wk = torch.zeros(d)
+    wk[:64] = 128.0 * torch.arange(64)
+    wk[64:68] = 8192.0 * torch.arange(4)
+    sd["blocks.11.attn.qkv.weight"][d:2 * d] = wk[None, :]
+    sd["blocks.11.attn.qkv.bias"][d:2 * d] = d + torch.arange(d, dtype=torch.float32)
+    model = DinoViT("dino_vits16", sd, DEV, torch.float16)
+    assert gp == model.patch_size
+    hp, wp = gh // gp, gw // gp
+    t = hp * wp + 1
+    rows = torch.zeros(t, d)
+    for tok in range(t):
+        rows[tok, [tok % 64, 64 + tok // 64, 128]] = 2.0 ** 15
+        rows[tok, [381, 382, 383]] = -(2.0 ** 15)
+    model._pos_cache[(hp * gp, wp * gp)] = (rows[0].to(DEV).contiguous(), rows[1:].to(DEV).contiguous())
+    img = synthetic.synthetic_image(5, gh, gw)                # the probe's image; its pixels must not matter
+    k = model.extract_k(torch.from_numpy(img[None]).to(DEV)).cpu().numpy()
+    n = hp * wp
+    assert k.shape == (1, n, d) and g["k"].shape == (1, n, gd)
+    expect = 1024.0 * np.arange(1, n + 1, dtype=np.float32)[:, None] + (d + np.arange(d, dtype=np.float32))[None, :]
+    assert np.array_equal(k[0], expect)
+    # the golden decodes to the same (token, column-of-the-K-third) table
+    tok_golden = (g["k"][0] - (gd + np.arange(gd, dtype=np.float32))[None, :]) / 1000.0
+    tok_ours = (k[0] - (d + np.arange(d, dtype=np.float32))[None, :]) / 1024.0
+    assert np.array_equal(tok_golden[:, 0], tok_ours[:, 0]) and np.array_equal(tok_ours[:, 0], np.arange(1, n + 1))
+    assert (tok_golden == tok_golden[:, :1]).all() and (tok_ours == tok_ours[:, :1]).all()
+
+
 @pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "0", "model": "dino_vitb16"},
                                  {"DSS_LINEAR_K384": "2", "model": "dino_vitb16"}])
 def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
@@ -149,6 +196,44 @@ def test_config3_vitb8_480_k15_end_to_end():
         assert info2.item() > 0
         check_eigs(vec2[0].cpu().numpy(), ev2[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"config3 eig-stage img{idx}",
                    d=build_w64(kr[0].numpy())[1], ext=ext)
+
+
+@pytest.mark.timeout(2400)
+def test_config5_upper_size_range_640_vitb8_k20():
+    """BASELINE config 5's UPPER size range through the whole path: dino_vitb8 at 640 x 640 (T = 6401 tokens, N = 6400
+    patches - the largest shape of the config) with K = 20, and an odd size above 480 px (523 x 637 -> 65 x 79 patches,
+    neither side a multiple of 8).  Per image: ViT features against the fp32 CPU oracle (patchify -> attention at
+    T > 3601 -> K projection); for the 640 x 640 image also the eigen stage on the ORACLE's features against the reference
+    recipe with its fp64 dense extension (`ref_laplacian_eigs_ext`: real eigenpairs at N = 6400, not only properties) and
+    the end-to-end eigenvectors against the all-fp32 CPU path - every eigenvalue cluster held to 1e-4."""
+    from dss_amd import spectral
+
+    model, ref = _models("dino_vitb8", 0, 0.0, torch.float16)
+    K = 20
+    for idx, h, w, full in ((71, 640, 640, True), (72, 523, 637, False)):
+        img = synthetic.synthetic_image(idx, h, w)
+        n = (h // 8) * (w // 8)
+        kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
+        if not full:
+            k = model.extract_k(torch.from_numpy(img)[None].to(DEV))
+            assert tuple(k.shape) == (1, n, 768)
+            assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
+            continue
+        k, ev, vec, info = pipeline.features_and_eigs(model, torch.from_numpy(img)[None].to(DEV), K)
+        assert info.item() > 0 and tuple(vec.shape) == (1, K, n) and tuple(k.shape) == (1, n, 768)
+        assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
+        lam, v, ext, draws = spectral_ref.ref_laplacian_eigs_ext(kr, K)
+        dref = build_w64(kr[0].numpy())[1]
+        ev2, vec2, info2 = spectral.laplacian_eigs_from_features(kr.to(DEV), K)
+        assert info2.item() > 0
+        check_eigs(vec2[0].cpu().numpy(), ev2[0].cpu().numpy(), v.numpy(), lam.numpy(), what="config5 640 eig-stage",
+                   d=dref, ext=ext)
+        report = []
+        check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what="config5 640 end to end",
+                   lam_tol=1e-3, d=dref, ext=ext, report=report)
+        print(f"[config5 640] N={n}: oracle draws={draws}; passes {int(info.item())}; worst cluster "
+              f"{max(r['err'] for r in report):.1e}; non-isolated: "
+              f"{[(r['first'], r['last'], r['kind']) for r in report if r['kind'] != 'isolated']}")
 
 
 @pytest.mark.timeout(900)

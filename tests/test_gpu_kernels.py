@@ -165,7 +165,8 @@ def _attention_ref(qkv, heads, scale):
 
 @pytest.mark.parametrize("b,t,heads", [(2, 901, 6), (1, 197, 6), (1, 17, 2), (1, 64, 1), (1, 65, 1), (3, 130, 12),
                                         (1, 1, 1), (1, 33, 3), (1, 3601, 2), (2, 257, 2), (1, 320, 1), (1, 513, 2),
-                                        (2, 545, 1), (1, 577, 3), (1, 96, 2), (1, 1025, 1)])
+                                        (2, 545, 1), (1, 577, 3), (1, 96, 2), (1, 1025, 1), (1, 6401, 2),
+                                        (1, 5136, 1)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_attention_matches_fp64_reference(b, t, heads, dtype):
     g = torch.Generator().manual_seed(b * 100 + t + heads)
