@@ -505,6 +505,206 @@ __global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __r
   store_tile(acc11, 32, 32);
 }
 
+
+// ================================================================================================
+// The pipeline's affinity build (round 3): features that come straight out of the ViT are handed over in f16 together
+// with their inverse norms (kfeatures_finalize_kernel below - the K projection's bias add, the CLS drop, the fp32
+// features the caller gets back, the f16 copy and 1 / |x| in ONE pass instead of two torch passes), and the Gram kernel
+// works from those:
+//   * why: gram_f16_fused (fp32 in, 128 x 128 tiles) was bound by the L2 -> CU path, not by HBM - every block pulled
+//     2 x 128 rows x D fp32 = 393 KB through the vector memory path for 16 K outputs, 28.7 GB per 2030-image launch
+//     against 4.45 GB of HBM traffic, converting while staging (cvt + dot2 + ds_write per element, two barriers per 32
+//     columns).  f16 rows halve those bytes, 256 x 128 tiles take another quarter off (10.8 GB), and the panels arrive by
+//     LDS-DMA: no staging registers, no conversion, one barrier per 32-column stage with two stages of DMA in flight.
+//   * workgroup = 8 waves (4 x 2) on a 256-row x 128-column tile, wave = 64 x 64 = one packed storage tile (64
+//     accumulator registers, 92 VGPRs: two workgroups per CU); transposed product as before (a lane owns rows of W, its
+//     registers run along the columns: 8-byte stores into the storage tile).
+//   * measured (2030 images, N = 900, D = 384): 2.43 ms for gram_f16_fused -> 1.51 ms.  What bounds it now is the request
+//     rate of the L2 -> LDS path, not HBM and not the MFMAs: 40 600 blocks x 12 stages x 24 KB = 11.7 GB in 64-byte row
+//     segments = 7.7 TB/s (~120 G requests/s; the fp32 kernel's full-line loads moved 12 TB/s at ~94 G/s).  A 256 x 256
+//     tile with 128 accumulator registers per wave (one workgroup per CU, 7.2 GB) measured the same 1.58 ms: fewer
+//     bytes, but nothing to run under a block's prologue and output stores.
+//   * the upper block triangle in these tiles: row block bi (storage-tile rows 4 bi ..) needs column blocks cj >= 2 bi.
+//   * LDS stage = [row panel 256 x 64 B][column panel 128 x 64 B] = 24 KB, a ring of three; one DMA piece = 16 rows x
+//     64 B, 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (swizzle on the SOURCE address): the 16 lanes of a
+//     ds_read_b128 group (16 rows, one chunk) hit the 16 slots of a bank row once.
+//   * epilogue: w = <x_i, x_j> r_i r_j with the inverse norms staged in LDS, relu + round(65535 w) by v_cvt_pknorm_u16,
+//     rows / columns >= N written as 0.
+// Algorithmic bytes per image: 2 N D (f16 features) + 4 N (norms) + N (N + 1) (the packed 16-bit upper triangle).
+static constexpr int G3R = 256;      // block tile rows
+static constexpr int G3C = 128;      // block tile columns
+static constexpr int G3K = 32;       // feature columns per stage (64-byte rows)
+
+__global__ __launch_bounds__(512, 4) void gram_f16_dma_kernel(const f16* __restrict__ feats, const float* __restrict__ rnorm,
+                                                              uint16_t* __restrict__ W, int N, int D, int ldw,
+                                                              size_t w_stride, int nimg, int nblk) {
+  constexpr int RING = 3;                                // stage buffers: two stages' DMA in flight while one is consumed
+  constexpr int RP = G3R * 64, CP = G3C * 64;            // bytes per row / column panel per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING][RP + CP];
+  __shared__ __attribute__((aligned(16))) float rn[G3R + G3C];   // inverse norms of the block's rows, then columns (0 past N)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nt = ldw / 64, ncj = (nt + 1) / 2;
+  int img, rem;
+  {  // XCD-aware order: all blocks of one image share an XCD
+    const int id = blockIdx.x, g8 = nimg & ~7;
+    if (id < nblk * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      img = (slot / nblk) * 8 + xcd;
+      rem = slot % nblk;
+    } else {
+      const int r = id - nblk * g8;
+      img = g8 + r / nblk;
+      rem = r % nblk;
+    }
+  }
+  int bi = 0, cj;                                        // row block bi holds column blocks 2 bi .. ncj - 1
+  while (rem >= ncj - 2 * bi) { rem -= ncj - 2 * bi; ++bi; }
+  cj = 2 * bi + rem;
+  const int I0 = bi * G3R, J0 = cj * G3C;
+  const f16* F = feats + (long)img * N * D;
+  const float* R = rnorm + (long)img * N;
+  uint16_t* Wb = W + img * w_stride;
+  const int ti = 4 * bi + wr, tj = 2 * cj + wc;          // this wave's storage tile
+  const bool compute = ti < nt && tj < nt && tj >= ti;
+
+  auto uniform_ptr = [](const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+  };
+  const unsigned char* fsrc = uniform_ptr(F);
+  typedef __attribute__((address_space(3))) void* lds3_t;
+  const unsigned lds0 = (unsigned)(size_t)(lds3_t)(&lds[0][0]);
+  auto dma16 = [&](unsigned off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(off), "s"(fsrc) : "memory");
+  };
+  // a stage = 16 + 8 pieces of 16 rows; wave w moves row pieces 2 w, 2 w + 1 and column piece w: 3 DMA instructions
+  const unsigned rowbytes = (unsigned)D * 2u;
+  auto issue = [&](int s) {
+    const unsigned sbase = lds0 + (unsigned)((s % RING) * (RP + CP));
+    const unsigned scol = (unsigned)(s * 64);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int piece = j < 2 ? 2 * wave + j : wave;      // piece of the row panel (j < 2) / of the column panel
+      const int r = 16 * piece + (lane >> 2);
+      const unsigned c = (unsigned)((lane & 3) ^ ((r >> 2) & 3));
+      int g = (j < 2 ? I0 : J0) + r;
+      g = g < N ? g : N - 1;                              // rows past N: finite data, zeroed on output
+      const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)((j < 2 ? 0 : RP) + piece * 1024));
+      dma16((unsigned)g * rowbytes + scol + 16u * c, dst);
+    }
+  };
+  const int ns = D / G3K;
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < ns) issue(s);
+  if (tid < G3R + G3C) {   // visible to everyone behind the first stage barrier
+    const int g = tid < G3R ? I0 + tid : J0 + tid - G3R;
+    rn[tid] = g < N ? R[g] : 0.f;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment byte offsets inside a panel: row (base + li), chunk 2 kk + hh at position ^ ((row >> 2) & 3)
+  // (row bases are multiples of 32, so the swizzle term depends on li only)
+  const unsigned sw = (unsigned)((li >> 2) & 3);
+  unsigned foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = (unsigned)(li * 64) + ((((unsigned)(2 * kk + hh)) ^ sw) << 4);
+
+  // One stage (8 MFMAs per wave) is far too short to cover an L2 / HBM round trip, so the DMA runs two stages ahead and
+  // the wait is counted: the younger stage's three pieces per wave stay in flight.
+  for (int s = 0; s < ns; ++s) {
+    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // stage s complete for everyone; buffer (s - 1) % RING is free
+    asm volatile("" ::: "memory");
+    if (s + RING - 1 < ns) issue(s + RING - 1);
+    if (compute) {
+      const unsigned char* rp = &lds[s % RING][0] + (wr * 64) * 64;
+      const unsigned char* cp = &lds[s % RING][RP] + (wc * 64) * 64;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const f16x8 r0 = *reinterpret_cast<const f16x8*>(rp + foff[kk]);                // row panel -> "B" operand
+        const f16x8 r1 = *reinterpret_cast<const f16x8*>(rp + 32 * 64 + foff[kk]);
+        const f16x8 c0 = *reinterpret_cast<const f16x8*>(cp + foff[kk]);                // column panel -> "A" operand
+        const f16x8 c1 = *reinterpret_cast<const f16x8*>(cp + 32 * 64 + foff[kk]);
+        acc[0][0] = mfma32x32x16(c0, r0, acc[0][0]);
+        acc[0][1] = mfma32x32x16(c1, r0, acc[0][1]);
+        acc[1][0] = mfma32x32x16(c0, r1, acc[1][0]);
+        acc[1][1] = mfma32x32x16(c1, r1, acc[1][1]);
+      }
+    }
+  }
+  if (!compute) return;
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  uint16_t* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int lrow = 32 * a + li;                         // this lane's row inside the tile
+    const float rr = rn[wr * 64 + lrow];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const f32x16& A = acc[a][b2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int lc = 32 * b2 + 8 * g + 4 * hh;          // 4 consecutive columns of the tile
+        const f32x4 rc = *reinterpret_cast<const f32x4*>(&rn[G3R + wc * 64 + lc]);
+        const u16x2 q0 = __builtin_amdgcn_cvt_pknorm_u16(A[4 * g] * rr * rc[0], A[4 * g + 1] * rr * rc[1]);
+        const u16x2 q1 = __builtin_amdgcn_cvt_pknorm_u16(A[4 * g + 2] * rr * rc[2], A[4 * g + 3] * rr * rc[3]);
+        const u32x2 out = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+        *reinterpret_cast<u32x2*>(tile + lrow * 64 + lc) = out;
+      }
+    }
+  }
+}
+
+// K projection output -> what the caller and the affinity build need, in one pass over the rows:
+//   kproj [B, T, D] f32 (the GEMM's raw output, token 0 = CLS) (+ bias [D])
+//   -> k32 [B, T-1, D] f32 (extract.py:96-98: CLS dropped), k16 the same rounded to f16, rnorm [B, T-1] = 1 / max(|x16|, eps)
+// (the norm of the ROUNDED row, so that w_ii = 1 exactly).  One wave per output row.
+__global__ __launch_bounds__(256) void kfeatures_finalize_kernel(const float* __restrict__ kproj, const float* __restrict__ bias,
+                                                                 float* __restrict__ k32, f16* __restrict__ k16,
+                                                                 float* __restrict__ rnorm, long rows_out, int T, int D,
+                                                                 float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int N = T - 1;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows_out; row += (long)gridDim.x * 4) {
+    const long b = row / N, n = row - b * N;
+    const float* src = kproj + (b * T + n + 1) * (long)D;
+    float* d32 = k32 + row * (long)D;
+    f16* d16 = k16 + row * (long)D;
+    float ss = 0.f;
+    for (int c = lane; c < (D >> 2); c += 64) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * c);
+      if (bias) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 4 * c);
+        v += bb;
+      }
+      *reinterpret_cast<f32x4*>(d32 + 4 * c) = v;
+      f16x4 h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { h[i] = (f16)v[i]; const float r = (float)h[i]; ss += r * r; }
+      *reinterpret_cast<f16x4*>(d16 + 4 * c) = h;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) rnorm[row] = 1.0f / fmaxf(sqrtf(ss), eps);
+  }
+}
+
 }  // namespace dss
 
 extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, void* stream) {
@@ -592,6 +792,36 @@ extern "C" int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, in
   hipLaunchKernelGGL(dss::gram_f16_fused_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, feats, W, N,
                      D, ldw, eps, dss_affinity_elems(N), B);
   DSS_CHECK_LAUNCH("gram_f16_fused");
+  return DSS_OK;
+}
+
+extern "C" int dss_affinity_f16_u16(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, int D, void* stream) {
+  DSS_REQUIRE(feats16 && rnorm && W, "dss_affinity_f16_u16: null pointer");
+  DSS_REQUIRE(B > 0 && N > 0 && D > 0, "dss_affinity_f16_u16: bad shape B=%d N=%d D=%d", B, N, D);
+  DSS_REQUIRE(D % dss::G3K == 0, "dss_affinity_f16_u16: feature dim must be a multiple of %d (got %d)", dss::G3K, D);
+  DSS_REQUIRE((long)N * D * 2 < 4294967296L, "dss_affinity_f16_u16: one image's features exceed the DMA's 32-bit offsets");
+  const int ldw = dss_affinity_ld(N);
+  const int nt = ldw / 64, ncj = (nt + 1) / 2;
+  int nblk = 0;                                           // row block bi (256 rows) x column blocks 2 bi .. ncj - 1 (128 columns)
+  for (int bi = 0; 2 * bi < ncj; ++bi) nblk += ncj - 2 * bi;
+  const long nblocks = (long)nblk * B;
+  DSS_REQUIRE(nblocks < 2147483647L, "dss_affinity_f16_u16: too many blocks (%ld)", nblocks);
+  hipLaunchKernelGGL(dss::gram_f16_dma_kernel, dim3((unsigned)nblocks), dim3(512), 0, (hipStream_t)stream,
+                     (const dss::f16*)feats16, rnorm, W, N, D, ldw, dss_affinity_elems(N), B, nblk);
+  DSS_CHECK_LAUNCH("gram_f16_dma");
+  return DSS_OK;
+}
+
+extern "C" int dss_kfeatures_finalize(const float* kproj, const float* bias, float* k32, void* k16, float* rnorm, int B,
+                                      int T, int D, float eps, void* stream) {
+  DSS_REQUIRE(kproj && k32 && k16 && rnorm, "dss_kfeatures_finalize: null pointer");
+  DSS_REQUIRE(B > 0 && T > 1 && D > 0 && D % 4 == 0, "dss_kfeatures_finalize: bad shape B=%d T=%d D=%d", B, T, D);
+  const long rows = (long)B * (T - 1);
+  long blocks = (rows + 3) / 4;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(dss::kfeatures_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, kproj, bias,
+                     k32, (dss::f16*)k16, rnorm, rows, T, D, eps);
+  DSS_CHECK_LAUNCH("kfeatures_finalize");
   return DSS_OK;
 }
 

@@ -41,6 +41,9 @@ SYMBOLS = {
                                    c_void_p]),
     "dss_affinity_split_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "dss_affinity_fused_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "dss_affinity_f16_u16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dss_kfeatures_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                       c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dss_laplacian_eigs_u16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                        c_int, c_void_p, c_size_t, c_void_p]),
@@ -339,6 +342,34 @@ def affinity_fused_u16(feats: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
         _check(load_library().dss_affinity_fused_u16(_dev(feats, "feats"), _dev(w, "W"), b, n, d, float(eps), _stream()),
                "dss_affinity_fused_u16")
     return w
+
+
+def affinity_f16_u16(feats16: torch.Tensor, rnorm: torch.Tensor) -> torch.Tensor:
+    """f16 ``[B, N, D]`` features + inverse row norms ``[B, N]`` (``kfeatures_finalize``) -> the packed 16-bit W of
+    ``affinity_fused_u16`` (``dss_affinity_f16_u16``: 256 x 256 tiles, panels by LDS-DMA)."""
+    assert feats16.dtype == torch.float16 and feats16.dim() == 3 and rnorm.dtype == torch.float32
+    b, n, d = feats16.shape
+    assert rnorm.numel() == b * n
+    w = torch.empty((b, affinity_elems(n)), dtype=torch.int16, device=feats16.device)
+    with _timed("affinity", b=b, n=n, d=d, w_bytes=2, f16_in=True):
+        _check(load_library().dss_affinity_f16_u16(_dev(feats16, "feats16"), _dev(rnorm, "rnorm"), _dev(w, "W"), b, n, d,
+                                                   _stream()), "dss_affinity_f16_u16")
+    return w
+
+
+def kfeatures_finalize(kproj: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-12):
+    """Raw K-projection output ``[B, T, D]`` f32 (+ ``bias [D]``) -> ``(k32 [B, T-1, D] f32, k16 the same in f16,
+    rnorm [B, T-1])`` in one pass (``dss_kfeatures_finalize``: bias add, CLS drop, f16 copy, inverse norms)."""
+    assert kproj.dtype == torch.float32 and kproj.dim() == 3
+    b, t, d = kproj.shape
+    k32 = torch.empty((b, t - 1, d), dtype=torch.float32, device=kproj.device)
+    k16 = torch.empty((b, t - 1, d), dtype=torch.float16, device=kproj.device)
+    rn = torch.empty((b, t - 1), dtype=torch.float32, device=kproj.device)
+    with _timed("kfeatures_finalize", b=b, t=t, d=d):
+        _check(load_library().dss_kfeatures_finalize(_dev(kproj, "kproj"), 0 if bias is None else _dev(bias, "bias"),
+                                                     _dev(k32, "k32"), _dev(k16, "k16"), _dev(rn, "rnorm"), b, t, d,
+                                                     float(eps), _stream()), "dss_kfeatures_finalize")
+    return k32, k16, rn
 
 
 EIGS_NORMALIZED_LAPLACIAN, EIGS_AFFINITY_LM, EIGS_LAPLACIAN = 0, 1, 2

@@ -20,7 +20,12 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
                       strict: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """``img_u8`` u8 ``[B, H, W, 3]`` on the GPU -> (k ``[B, N, D]``, eigenvalues ``[B, K]``,
     eigenvectors ``[B, K, N]``, info ``[B]``)."""
-    k = model.extract_k(img_u8, which_block=which_block)
+    mode = os.environ.get("DSS_AFFINITY", "fused")
+    k16 = rn = None
+    if mode == "fused" and normalize and threshold_at_zero:
+        k, k16, rn = model.extract_k_f16(img_u8, which_block=which_block)
+    else:
+        k = model.extract_k(img_u8, which_block=which_block)
     # the features just came out of the half-precision ViT (relative error ~1e-3): the fused affinity build, which rounds
     # them to f16 (2^-11) on its way into the MFMAs, costs nothing in accuracy here.  Its own tolerance, for callers with
     # EXACT fp32 features: |dW| <= 5e-5, eigenvalues within ~6e-5 of the fp32 build - looser than the 1e-5 eigenvalue bar
@@ -29,7 +34,7 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
     # all-fp32 CPU path (bench.py `parity`, eigenvalue_tol 1e-3).
     ev, vec, info = spectral.laplacian_eigs_from_features(k, K, normalize=normalize,
                                                           threshold_at_zero=threshold_at_zero, strict=strict,
-                                                          affinity_mode=os.environ.get("DSS_AFFINITY", "fused"))
+                                                          affinity_mode=mode, feats16=k16, rnorm=rn)
     return k, ev, vec, info
 
 

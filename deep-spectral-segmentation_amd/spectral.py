@@ -98,7 +98,8 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
                                  affinity_mode: Optional[str] = None, retry: bool = True,
                                  problem: str = "laplacian",
                                  upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None,
-                                 w_dtype: Optional[str] = None
+                                 w_dtype: Optional[str] = None,
+                                 feats16: Optional[torch.Tensor] = None, rnorm: Optional[torch.Tensor] = None
                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
     ``(eigenvalues [B, K], eigenvectors [B, K, N], info [B])``, all on the GPU.
@@ -121,6 +122,10 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
       ``bench.py`` use it - and the split build otherwise.  With the default recipe (``problem="laplacian"``,
       ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``w_dtype="f32"`` /
       ``$DSS_W_DTYPE=f32`` keeps floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
+    * ``feats16`` / ``rnorm``: the f16 copy of ``feats`` and its inverse row norms (``hip.kfeatures_finalize``: the
+      hand-over of a ViT that ran just before, ``DinoViT.extract_k_f16``).  With them the ``"fused"`` build of the
+      default recipe starts from the f16 rows (``hip.affinity_f16_u16``: half the bytes through the L2, panels by
+      LDS-DMA) - the same arithmetic as ``hip.affinity_fused_u16``, which rounds to f16 itself.
     * ``retry``: images that exhaust their restart budget are re-solved once with the largest Krylov space.
       Checking for them reads ``info`` back (one device->host sync per call): throughput loops that must keep
       the host running ahead pass ``retry=False, strict=False`` and inspect ``info`` once at the end.
@@ -185,7 +190,10 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
                 f = hip.normalize_rows(f)
             w = hip.affinity(f, threshold_at_zero)
         elif w_u16 and affinity_mode == "fused" and d >= 256:   # raw features -> packed 16-bit W in one kernel
-            w = hip.affinity_fused_u16(f)
+            if feats16 is not None and rnorm is not None:
+                w = hip.affinity_f16_u16(feats16[s:s + chunk].contiguous(), rnorm[s:s + chunk].contiguous())
+            else:
+                w = hip.affinity_fused_u16(f)
         else:  # split-f16 (fp32-class accuracy, ~1e-7), HBM-bound; fused with the row normalisation
             w = hip.affinity_split(f, normalize, threshold_at_zero, u16=w_u16)
         ev, vec, info = hip.laplacian_eigs(w, n, K, ncv=ncv, tol=tol, max_restarts=max_restarts,

@@ -226,7 +226,15 @@ class DinoViT:
         return F.layer_norm(cls, (self.embed_dim,), self.norm_w, self.norm_b, LN_EPS)
 
     @torch.no_grad()
-    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1) -> torch.Tensor:
+    def extract_k_f16(self, img_u8: torch.Tensor, which_block: int = -1):
+        """``extract_k`` for a consumer that stays on the GPU (``pipeline.features_and_eigs``): returns
+        ``(k [B, N, D] fp32, k16 the same in f16, rnorm [B, N] = 1 / |k16 row|)`` - the hand-over of
+        ``hip.kfeatures_finalize`` (bias add, CLS drop, f16 copy and inverse norms in one pass) that the f16-input
+        affinity build (``hip.affinity_f16_u16``) starts from."""
+        return self.extract_k(img_u8, which_block, _finalize=True)
+
+    @torch.no_grad()
+    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1, _finalize: bool = False) -> torch.Tensor:
         """``img_u8``: u8 ``[B, H, W, 3]`` RGB on the GPU (uncropped).  Returns the hooked K features
         ``[B, N, D]`` fp32, ``N = (H//P)*(W//P)``, rows in row-major patch order, CLS removed."""
         assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
@@ -248,8 +256,13 @@ class DinoViT:
         else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
             hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
+            if _finalize and n > 0:
+                return hip.kfeatures_finalize(k, blk["k_b32"])
             k += blk["k_b32"]
-        return k[:, 1:, :].contiguous()
+        k = k[:, 1:, :].contiguous()
+        if _finalize:   # the all-fp32 K projection (or a degenerate grid): same hand-over, no extra bias
+            return hip.kfeatures_finalize(torch.cat((k[:, :1], k), dim=1), None)
+        return k
 
 
 def wave_filling_batch(tokens: int, target: int = 256, rows_per_workgroup: int = 512,

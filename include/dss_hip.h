@@ -132,6 +132,19 @@ int dss_affinity_split_u16(const float* feats, uint16_t* W, int B, int N, int D,
  * goldens move by <= 3e-6 in cosine.  D % 32 == 0.  extract/extract.py:148,191-193. */
 int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, int N, int D, float eps, void* stream);
 
+/* The same build for features that never were fp32 on the way in - the in-memory pipeline, where the K projection hands
+ * its output over through dss_kfeatures_finalize: f16 features [B, N, D] + their inverse norms [B, N] in, packed 16-bit W
+ * out.  256 x 256 block tiles, panels by LDS-DMA (affinity.hip: gram_f16_dma_kernel).  Algorithmic bytes per image:
+ * 2 N D + 4 N in, 2 * dss_affinity_elems(N) out.  D % 32 == 0.  extract/extract.py:148,191-193. */
+int dss_affinity_f16_u16(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, int D, void* stream);
+
+/* a7/a10 hand-over between the two stages when they run back to back in HBM (extract/extract.py:96-98,148): the raw fp32
+ * output of the last block's K projection kproj [B, T, D] (token 0 = CLS; + bias [D] unless NULL) -> k32 [B, T-1, D] fp32
+ * (the hooked features, CLS dropped: what extract_features saves), k16 the same rounded to f16, rnorm [B, T-1] =
+ * 1 / max(|k16 row|, eps).  One pass; replaces a bias add and a strided copy. */
+int dss_kfeatures_finalize(const float* kproj, const float* bias, float* k32, void* k16, float* rnorm, int B, int T, int D,
+                           float eps, void* stream);
+
 /* ---- a13-a15: degree, normalised Laplacian, K smallest generalized eigenpairs, sign rule -------
  * extract/extract_utils.py:207-220  d = W 1 ; d[d < 1e-12] = 1
  * extract/extract.py:227            eigsh(D - W, k=K, sigma=0, which='LM', M=D)

@@ -33,6 +33,12 @@ for STAGE in "$@"; do
     tests_all) timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
     tests_attn) timeout 900 python -m pytest tests -m gpu -q --timeout 600 -rf --tb=short -k "attention or vit" 2>&1 | tail -40 > gpurun_out/pytest_attn.log; tail -25 gpurun_out/pytest_attn.log;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -4 gpurun_out/smoke.log;;
+    bench_quick) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS:-} 2> gpurun_out/bench_quick.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print({k: d[k] for k in ('value', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_in_loop_ms_per_step')})
+for k, v in d['kernels'].items(): print(k, v.get('launches'), v.get('avg_ms'), v.get('frac'), v.get('passes_per_image', ''))
+"; tail -2 gpurun_out/bench_quick.err;;
     bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
     *) echo "unknown stage $STAGE";;
   esac

@@ -305,6 +305,45 @@ def test_affinity_matches_fp64(b, n, d):
     assert (wr[:, :n, :n].double() - rr).abs().max().item() < 2e-6 * max(1.0, rr.max().item())
 
 
+@pytest.mark.parametrize("b,n,d", [(2, 900, 384), (1, 713, 384), (1, 16, 32), (1, 65, 32), (3, 129, 768), (9, 300, 384),
+                                    (1, 3600, 768), (1, 6400, 768)])
+def test_affinity_from_f16_handover(b, n, d):
+    """The pipeline's affinity build: `kfeatures_finalize` (K-projection output + bias -> fp32 features without the CLS
+    row, their f16 copy, inverse norms of the ROUNDED rows) followed by `affinity_f16_u16` (256 x 256 tiles, LDS-DMA
+    panels) - against fp64 on the exact features and, entry by entry, against the one-kernel build from fp32."""
+    g = torch.Generator().manual_seed(n + d)
+    feats = torch.from_numpy(np.stack([synthetic.synthetic_features("blobs" if i % 2 else "random", n, d, 70 + i,
+                                                                     None if int(n ** 0.5) ** 2 == n else (1, n))
+                                       for i in range(b)]))
+    bias = torch.randn(d, generator=g) * 0.1
+    kproj = torch.cat((torch.randn(b, 1, d, generator=g), feats - bias), dim=1)        # token 0 = CLS, bias not yet added
+    k32, k16, rn = hip.kfeatures_finalize(kproj.to(DEV), bias.to(DEV))
+    want = (kproj[:, 1:] + bias)
+    assert torch.equal(k32.cpu(), want) and torch.equal(k16.cpu(), want.half())
+    assert (rn.cpu().double() - 1.0 / want.half().double().norm(dim=-1)).abs().max().item() <= 2e-6 * rn.max().item()
+    wq_packed = hip.affinity_f16_u16(k16, rn)
+    ld = hip.affinity_ld(n)
+    assert wq_packed.dtype == torch.int16 and tuple(wq_packed.shape) == (b, hip.affinity_elems(n))
+    wq = hip.affinity_to_dense(wq_packed, n).cpu()
+    assert torch.equal(wq[:, :, n:], torch.zeros(b, ld, ld - n)) and torch.equal(wq[:, n:, :], torch.zeros(b, ld - n, ld))
+    x = F.normalize(want.double(), dim=-1)
+    ref = (x @ x.transpose(1, 2)).clamp_min(0)
+    assert (wq[:, :n, :n].double() - ref).abs().max().item() <= 1e-4 * max(1.0, (384 / d) ** 0.5)
+    assert (wq[:, :n, :n].double() - ref).abs().mean().item() <= 1e-5 * max(1.0, (384 / d) ** 0.5)
+    assert wq.min().item() >= 0.0 and wq.max().item() <= 1.0
+    assert abs(torch.diagonal(wq[:, :n, :n], dim1=1, dim2=2).min().item() - 1.0) < 2e-5
+    assert (wq - wq.transpose(1, 2)).abs().max().item() <= 1.01 / 65535
+    if d >= 256:   # the same operands as the one-kernel build from fp32 (it rounds to f16 itself): at most one step apart
+        wf = hip.affinity_to_dense(hip.affinity_fused_u16(k32), n).cpu()
+        assert (wq - wf).abs().max().item() <= 2.01 / 65535
+    # zero row: eps keeps the inverse norm finite, its similarities are 0
+    kz = kproj.clone()
+    kz[0, 3] = -bias
+    k32z, k16z, rnz = hip.kfeatures_finalize(kz.to(DEV), bias.to(DEV))
+    wz = hip.affinity_to_dense(hip.affinity_f16_u16(k16z, rnz), n).cpu()
+    assert torch.isfinite(rnz).all() and wz[0, 2].abs().max().item() == 0.0 and wz[0, :, 2].abs().max().item() == 0.0
+
+
 # ----------------------------------------------------------------------------- eigen stage
 EIG_FILES = sorted(glob.glob(str(HERE / "golden" / "eigs_*.npz")))
 
