@@ -169,51 +169,85 @@ def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
 
 
 class ImageFeeder:
-    """The u8 images of every step travel host -> HBM inside the timed region: a pinned host pool of ``n_distinct``
-    images, two device batches, a copy stream.  ``prefetch(s)`` enqueues the copies of step s (contiguous runs of the
-    pool, so the PCIe volume is the full batch, with no host-side assembly); ``get(s)`` makes the compute stream wait for
-    them; ``release(s)`` marks the batch free once the step's kernels have been enqueued."""
+    """The u8 images travel host -> HBM inside the timed region, at the granularity of ONE ViT forward: a pinned host pool
+    of ``n_distinct`` images, a ring of device buffers of ``chunk`` images, a copy stream.  ``prefetch(c, count)`` enqueues
+    the copy of global chunk ``c`` (a contiguous run of the pool, so the PCIe volume is the full chunk, with no host-side
+    assembly); ``get(c, count)`` makes the compute stream wait for it; ``release(c)`` marks the buffer free once the
+    forward that reads it has been enqueued.  The copy of forward i + 1 runs under forward i, and a run (or a rank's
+    shard) starts computing after its FIRST forward's images have arrived, not after a whole step's."""
 
-    def __init__(self, host_pool: torch.Tensor, batch: int, dev, resident: bool = False):
-        self.pool, self.batch, self.n = host_pool, batch, host_pool.shape[0]
+    NBUF = 3
+
+    def __init__(self, host_pool: torch.Tensor, chunk: int, dev, resident: bool = False):
+        self.pool, self.chunk, self.n = host_pool, chunk, host_pool.shape[0]
         self.resident = resident
         if resident:
             self.dev_pool = host_pool.to(dev)
             return
-        self.bufs = [torch.empty((batch, *host_pool.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.bufs = [torch.empty((chunk, *host_pool.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(self.NBUF)]
         self.stream = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.free = [None, None]
+        self.ready = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.free = [None] * self.NBUF
 
-    def prefetch(self, s: int, count: int = 0):
+    def prefetch(self, c: int, count: int = 0):
         if self.resident:
             return
-        b = s & 1
-        count = count or self.batch
+        b = c % self.NBUF
+        count = count or self.chunk
         with torch.cuda.stream(self.stream):
             if self.free[b] is not None:
                 self.stream.wait_event(self.free[b])
-            j, off = 0, (s * self.batch) % self.n
+            j, off = 0, (c * self.chunk) % self.n
             while j < count:
                 run = min(self.n - off, count - j)
                 self.bufs[b][j:j + run].copy_(self.pool[off:off + run], non_blocking=True)
                 j, off = j + run, (off + run) % self.n
             self.ready[b].record(self.stream)
 
-    def get(self, s: int, count: int = 0):
-        count = count or self.batch
+    def get(self, c: int, count: int = 0):
+        count = count or self.chunk
         if self.resident:
-            idx = (torch.arange(count, device=self.dev_pool.device) + s * self.batch) % self.n
+            idx = (torch.arange(count, device=self.dev_pool.device) + c * self.chunk) % self.n
             return self.dev_pool[idx]
-        torch.cuda.current_stream().wait_event(self.ready[s & 1])
-        return self.bufs[s & 1][:count]
+        torch.cuda.current_stream().wait_event(self.ready[c % self.NBUF])
+        return self.bufs[c % self.NBUF][:count]
 
-    def release(self, s: int):
+    def release(self, c: int):
         if self.resident:
             return
         ev = torch.cuda.Event()
         ev.record()
-        self.free[s & 1] = ev
+        self.free[c % self.NBUF] = ev
+
+
+def chunk_counts(cnt: int, vit_batch: int):
+    """Images per ViT forward of a step of ``cnt`` images."""
+    return [min(vit_batch, cnt - s) for s in range(0, cnt, vit_batch)]
+
+
+def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16"):
+    """One step whose images arrive through the feeder: forward j reads global chunk ``c0 + j``; before it is enqueued the
+    copy of the NEXT chunk (this step's, or ``nxt`` = (chunk id, count) of the following step's first) is put on the copy
+    stream.  Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
+    counts = chunk_counts(cnt, vit_batch)
+    mode = os.environ.get("DSS_AFFINITY", "fused")
+    f16 = mode == "fused" and w_dtype == "u16"
+    parts = []
+    for j, n in enumerate(counts):
+        if j + 1 < len(counts):
+            feeder.prefetch(c0 + j + 1, counts[j + 1])
+        elif nxt is not None:
+            feeder.prefetch(*nxt)
+        imgs = feeder.get(c0 + j, n)
+        parts.append(model.extract_k_f16(imgs) if f16 else (model.extract_k(imgs),))
+        feeder.release(c0 + j)
+    cat = lambda i: torch.cat([p_[i] for p_ in parts]) if len(parts) > 1 else parts[0][i]
+    if f16:
+        out = spectral.laplacian_eigs_from_features(cat(0), K, strict=False, retry=False, w_dtype=w_dtype,
+                                                    affinity_mode=mode, feats16=cat(1), rnorm=cat(2))
+    else:
+        out = spectral.laplacian_eigs_from_features(cat(0), K, strict=False, retry=False, w_dtype=w_dtype, affinity_mode=mode)
+    return (*out, len(counts))
 
 
 def summarize_timers(timers, n_patches, dim, depth_attn):
@@ -335,10 +369,10 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol,
              "non_isolated_clusters_per_image": clusters})
 
 
-def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_step=0):
-    """The timed region for this rank: ``len(counts)`` steps (``counts[s]`` images each), H2D prefetched one step ahead,
-    every step's results streamed to pinned host memory, one collection on rank 0 at the end.  Returns
-    (elapsed seconds, host-enqueue seconds, info tensors, gathered (meta, payload) or None)."""
+def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_chunk=0):
+    """The timed region for this rank: ``len(counts)`` steps (``counts[s]`` images each), the u8 images copied H2D one ViT
+    forward ahead of their use, every step's results streamed to pinned host memory, one collection on rank 0 at the end.
+    Returns (elapsed seconds, host seconds inside the loop, info tensors, gathered (meta, payload) or None, chunks used)."""
     dev = model.device
     width = a.K * n_patches + a.K
     host_out = torch.empty((len(counts), max(counts), width), dtype=torch.float32, pin_memory=True)
@@ -348,14 +382,24 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_s
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    feeder.prefetch(first_step, counts[0])
+    chunk = first_chunk
+    feeder.prefetch(chunk, chunk_counts(counts[0], a.vit_batch)[0])
     base = 0
     for s, cnt in enumerate(counts):
-        if s + 1 < len(counts):
-            feeder.prefetch(first_step + s + 1, counts[s + 1])
-        imgs = feeder.get(first_step + s, cnt)
-        ev, vec, info = step(model, imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
-        feeder.release(first_step + s)
+        nchunks = len(chunk_counts(cnt, a.vit_batch))
+        nxt = (chunk + nchunks, chunk_counts(counts[s + 1], a.vit_batch)[0]) if s + 1 < len(counts) else None
+        if a.overlap or a.vit_streams > 1:   # the opt-in variants take a whole step's images at once
+            imgs = torch.cat([feeder.get(chunk + j, n) for j, n in enumerate(chunk_counts(cnt, a.vit_batch))])
+            ev, vec, info = step(model, imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
+            for j in range(nchunks):
+                feeder.release(chunk + j)
+                if j + 1 < nchunks:
+                    feeder.prefetch(chunk + j + 1, chunk_counts(cnt, a.vit_batch)[j + 1])
+            if nxt is not None:
+                feeder.prefetch(*nxt)
+        else:
+            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype)
+        chunk += nchunks
         ids = (torch.arange(cnt, device=dev, dtype=torch.int64) + base) * world + rank   # global round-robin item ids
         base += cnt
         meta, flat = distributed.pack_records(ids, ev, vec)
@@ -379,7 +423,7 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_s
         tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    return elapsed, host_enqueue_s, infos, gathered
+    return elapsed, host_enqueue_s, infos, gathered, chunk
 
 
 def main():
@@ -430,23 +474,39 @@ def main():
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:   # numpy releases the GIL: ~40 ms/image serial
         host = torch.from_numpy(np.stack(list(ex.map(lambda i: synthetic.synthetic_image(rank + world * i, a.size, a.size),
                                                      range(n_distinct))))).pin_memory()
-    feeder = ImageFeeder(host, a.batch, dev, resident=a.resident)
+    feeder = ImageFeeder(host, a.vit_batch, dev, resident=a.resident)
+    chunk_pos = 0                        # global chunk counter: every warm-up / timed step consumes its own chunks
+
+    def warm_step(m, w_dtype):
+        """One untimed step through the same feeder path as the timed region."""
+        nonlocal chunk_pos
+        feeder.prefetch(chunk_pos, chunk_counts(a.batch, a.vit_batch)[0])
+        if a.overlap or a.vit_streams > 1:
+            cc = chunk_counts(a.batch, a.vit_batch)
+            parts = []
+            for j, n in enumerate(cc):
+                parts.append(feeder.get(chunk_pos + j, n).clone())
+                feeder.release(chunk_pos + j)
+                if j + 1 < len(cc):
+                    feeder.prefetch(chunk_pos + j + 1, cc[j + 1])
+            out = step(m, torch.cat(parts), a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
+            chunk_pos += len(cc)
+            return out
+        ev, vec, info, used = step_fed(m, feeder, chunk_pos, a.batch, None, a.K, a.vit_batch, w_dtype)
+        chunk_pos += used
+        return ev, vec, info
 
     from dss_amd.vit import setup_gemm_tuning
     setup_gemm_tuning(tune_new_shapes=True)   # warm-up may pick GEMM solutions for shapes missing from the shipped table
     t_warm = time.perf_counter()
     n_warm, warm = 0, None
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
-        feeder.prefetch(n_warm)
-        warm = step(model, feeder.get(n_warm), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
-        feeder.release(n_warm)
+        warm = warm_step(model, a.w_dtype)
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
     if world > 1 and warm is None:   # --warmup 0: the collection warm-up below still needs one step's results
-        feeder.prefetch(0)
-        warm = step(model, feeder.get(0), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
-        feeder.release(0)
+        warm = warm_step(model, a.w_dtype)
     if world > 1:
         # warm the COLLECTION path too: RCCL sets up its point-to-point channels (one per peer) on first use - seconds,
         # not part of any steady state - so one full-size collection of a warm-up step's results runs before the clock
@@ -458,16 +518,19 @@ def main():
 
     # what the HOST needs to enqueue one step (all launches of the ViT forwards + affinity + eigensolver) when the queue
     # is empty and nothing blocks it: the ceiling the launch path alone would impose
+    warm_imgs = host[: min(a.batch, host.shape[0])].to(dev)
+    if warm_imgs.shape[0] < a.batch:
+        warm_imgs = warm_imgs.repeat((a.batch + warm_imgs.shape[0] - 1) // warm_imgs.shape[0], 1, 1, 1)[: a.batch]
     torch.cuda.synchronize()
     t_h = time.perf_counter()
-    step(model, feeder.get(n_warm - 1) if n_warm > 0 else host[: a.batch].to(dev), a.K, a.vit_batch, a.overlap,
-         a.vit_streams, a.w_dtype)
+    step(model, warm_imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
     host_only_ms = (time.perf_counter() - t_h) * 1e3
+    del warm_imgs
     torch.cuda.synchronize()
 
     hip.TIMERS = {}
-    elapsed, host_enqueue_s, infos, gathered = run_steps(model, feeder, counts, a, rank, world, n_patches, a.w_dtype,
-                                                         first_step=n_warm)
+    elapsed, host_enqueue_s, infos, gathered, chunk_pos = run_steps(model, feeder, counts, a, rank, world, n_patches,
+                                                                    a.w_dtype, first_chunk=chunk_pos)
     timers, hip.TIMERS = hip.TIMERS, None
     n_images = sum(counts)
     if world > 1:
@@ -526,22 +589,20 @@ def main():
     if world == 1 and a.companion_steps > 0 and a.dataset == 0:
         other = "f32" if a.w_dtype == "u16" else "u16"
         for i in range(2):   # warm the other storage's kernels / allocations
-            feeder.prefetch(i)
-            step(model, feeder.get(i), a.K, a.vit_batch, a.overlap, a.vit_streams, other)
-            feeder.release(i)
+            warm_step(model, other)
         torch.cuda.synchronize()
-        e2, _, _, _ = run_steps(model, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, other)
+        e2, _, _, _, chunk_pos = run_steps(model, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, other,
+                                           first_chunk=chunk_pos)
         out[f"value_w_{other}"] = round(a.companion_steps * a.batch / e2, 2)
     if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu)
         for i in range(2):
-            feeder.prefetch(i)
-            step(dl, feeder.get(i), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
-            feeder.release(i)
+            warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()
-        e3, _, inf3, _ = run_steps(dl, feeder, [a.batch] * a.dino_like_steps, a, rank, world, n_patches, a.w_dtype)
+        e3, _, inf3, _, chunk_pos = run_steps(dl, feeder, [a.batch] * a.dino_like_steps, a, rank, world, n_patches,
+                                              a.w_dtype, first_chunk=chunk_pos)
         inf3 = torch.cat(inf3)
         out["value_dino_like_weights"] = round(a.dino_like_steps * a.batch / e3, 2)
         out["passes_per_image_dino_like_weights"] = round(float(inf3.abs().float().mean().item()), 2)

@@ -39,6 +39,11 @@ d = json.loads(sys.stdin.read())
 print({k: d[k] for k in ('value', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_in_loop_ms_per_step')})
 for k, v in d['kernels'].items(): print(k, v.get('launches'), v.get('avg_ms'), v.get('frac'), v.get('passes_per_image', ''))
 "; tail -2 gpurun_out/bench_quick.err;;
+    bench_ds) for DS in ${DATASETS:-1250 10000}; do timeout 600 python bench.py --dataset $DS --cpu-images 0 --dino-like-steps 0 --companion-steps 0 2> gpurun_out/bench_ds$DS.err > gpurun_out/bench_ds$DS.json; python -c "
+import sys, json
+d = json.loads(open('gpurun_out/bench_ds$DS.json').read())
+print('dataset $DS:', {k: d[k] for k in ('value', 'ms_per_step', 'steps', 'scaling')}, d['config']['workload'])
+"; done;;
     bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
     *) echo "unknown stage $STAGE";;
   esac
