@@ -34,33 +34,40 @@
 namespace dss {
 
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
-static constexpr int LWAVES = 8;          // two per SIMD
-static constexpr int LTHREADS = 64 * LWAVES;
 static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
 
 // KS = K / 16 MFMA k-steps held per token row; RT = 32-row tiles per wave.  KS * RT = 48 fragments = 192 VGPRs.
-template <int KS, int RT> struct LinCfg {
-  static_assert(KS * RT == 48 && KS % LWAVES == 0, "the A operand of a wave is 48 fragments");
+// NW = waves per workgroup.  K = 384: FOUR waves (one per SIMD) and 80 KB of LDS - TWO workgroups share a CU, the SIMD's two
+// waves belong to different workgroups at different points of their row blocks (one's A prologue and epilogues can run
+// under the other's MFMAs).  Measured EQUAL to the eight-wave workgroup of rounds 1-2 (qkv 258 vs 255-272 us, fc1+GELU
+// 425-451 vs 435-453; scripts/debug/linear_ab.py) and kept for the smaller LDS footprint; K = 768 keeps eight waves (its
+// 96 KB of W buffers admit one workgroup per CU either way).  What the lab's ablations say about this kernel (same script,
+// DSS_LIN_ABL builds): no epilogue 209 us, no stores 222 us, every A fragment the SAME 16 bytes 130 us - but that last
+// build also feeds the MFMAs constant operands, and on this part a dense MFMA stream runs 2.2-2.5 PFLOP/s on constant
+// operands against 1.68 on random ones (profiles/r01_mfma_ceiling_probe.txt): the number is a clock effect as much as an
+// A-stream effect, and neither full-line LDS-DMA loads of A nor two workgroups per CU moved the real-data time.
+template <int KS, int RT, int NW> struct LinCfg {
+  static_assert(KS * RT == 48 && KS % NW == 0, "the A operand of a wave is 48 fragments");
+  static constexpr int WAVES = NW, THREADS = 64 * NW;
   static constexpr int K = 16 * KS;
   static constexpr int ROWS_WAVE = 32 * RT;
-  static constexpr int ROWS = ROWS_WAVE * LWAVES;           // token rows per workgroup
+  static constexpr int ROWS = ROWS_WAVE * NW;               // token rows per workgroup
   static constexpr int CHUNK_BYTES = LBN * K * 2;           // 24 KB (K = 384) / 48 KB (K = 768), double buffered
   static constexpr int PATCH_BYTES = ROWS_WAVE * 128;       // transpose patch of one wave: two chunks of f16
-  static constexpr int MAXN = KS == 24 ? 2048 : 3072;       // bias table in LDS (fp32)
+  static constexpr int MAXN = KS == 24 ? 2048 : 3072;       // widest layer of the model family
   static constexpr int NSTORE = 4 * RT;                     // 16-byte stores per lane per finished 64-column group
 };
 
-template <class T, bool GELU, int KS, int RT>
-__global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __restrict__ A, const T* __restrict__ W,
+template <class T, bool GELU, int KS, int RT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                                  const T* __restrict__ bias, T* __restrict__ C,
                                                                  int M, int N, int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
-  typedef LinCfg<KS, RT> Cfg;
-  constexpr int LK = Cfg::K, LKS = KS, LBM = Cfg::ROWS;
+  typedef LinCfg<KS, RT, NW> Cfg;
+  constexpr int LK = Cfg::K, LKS = KS, LBM = Cfg::ROWS, LWAVES = NW, LTHREADS = Cfg::THREADS;
   __shared__ __attribute__((aligned(256))) unsigned char Ws[2][Cfg::CHUNK_BYTES];
   __shared__ __attribute__((aligned(256))) unsigned char Stg[LWAVES][Cfg::PATCH_BYTES];
-  __shared__ __attribute__((aligned(16))) float Bs[Cfg::MAXN];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
@@ -69,15 +76,55 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
   const bool block_full = mrem >= LBM;
 
   // ---- this lane's RT token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ----------------------------
+  // Through the wave's own LDS patch, 64 columns at a time: LDS-DMA pieces of 8 rows x 128 B (FULL lines of A, 8 lanes per
+  // row; 16-byte chunk c of row r lands at position c ^ ((r >> 1) & 7): the swizzle is applied to the source address) and
+  // conflict-free ds_read_b128 of the fragments.  Rounds 1-2 loaded the fragments straight from global memory - lane
+  // (li, hh) 16 bytes of row li, a wave-instruction touching 32 rows x 32 B, 1536 partial-line requests per wave where 384
+  // full lines do; measured equal in time (see LinCfg), kept for the 4x fewer L2 requests.
   V8 a[RT][LKS];
+  {
+    typedef __attribute__((address_space(3))) void* lds3_t;
+    const unsigned long long abase = (unsigned long long)(A + (long)blockIdx.x * LBM * LK);
+    const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)abase), ahi = __builtin_amdgcn_readfirstlane((unsigned)(abase >> 32));
+    const unsigned char* asrc = reinterpret_cast<const unsigned char*>(((unsigned long long)ahi << 32) | alo);
+    const unsigned pdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds3_t)(&Stg[wave][0]));
+    constexpr int NPIECE = Cfg::ROWS_WAVE / 8;             // 1 KB pieces per 64-column round: 8 (K = 384) / 4 (K = 768)
+    constexpr int NROUND = LK / 64;
+    unsigned rowoff[NPIECE];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    const long r = (long)blockIdx.x * LBM + min(rloc + 32 * t + li, mrem - 1);
+    for (int q = 0; q < NPIECE; ++q) {
+      const int rowp = 8 * q + (lane >> 3);
+      const unsigned ch = (unsigned)((lane & 7) ^ ((rowp >> 1) & 7));
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 1)   // lab ablation: no A stream (every piece re-reads the block's first row)
+      rowoff[q] = 16u * ch;
+#else
+      rowoff[q] = (unsigned)min(rloc + rowp, mrem - 1) * (unsigned)(LK * 2) + 16u * ch;
+#endif
+    }
+    const unsigned char* pw = &Stg[wave][0];
+    const unsigned fsw = (unsigned)((li >> 1) & 7);
 #pragma unroll
-    for (int s = 0; s < LKS; ++s)
-      // plain loads: a 128-byte line of A is touched by 8 of these instructions (4 k-steps x 2 halves); with
-      // non-temporal loads it is re-fetched from HBM each time (measured: qkv 255 -> 291 us)
-      a[t][s] = *reinterpret_cast<const V8*>(A + r * LK + 16 * s + 8 * hh);
+    for (int rd = 0; rd < NROUND; ++rd) {
+#pragma unroll
+      for (int q = 0; q < NPIECE; ++q) {
+        unsigned keep;
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 1)
+        const unsigned off = rowoff[q];
+#else
+        const unsigned off = rowoff[q] + 128u * rd;
+#endif
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(pdst + 1024u * q), "v"(off), "s"(asrc) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+          a[t][4 * rd + sl] = *reinterpret_cast<const V8*>(pw + (32 * t + li) * 128 + ((((unsigned)(2 * sl + hh)) ^ fsw) << 4));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers before the next round lands
+    }
   }
 
   // ---- W chunk staging by LDS-DMA: instruction j of wave w stages k-step s = NST w + j (64 lanes x 16 B = 1 KB):
@@ -123,7 +170,10 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
     }
   };
 
-  for (int i = tid; i < N; i += LTHREADS) Bs[i] = to_f32<T>(bias[i]);
+  // bias of this lane's column in the chunk, fetched one chunk ahead (a plain load: hipcc waits for it at its first use,
+  // the START of the next chunk's MFMA phase, right behind wait_dma + barrier where nothing younger is in flight)
+  T bias_next = bias[li];
+  (void)LTHREADS;
 
   // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
   //      p ^ ((r >> 1) & 7): writes 2-way, reads conflict-free) + (uniform base, 32-bit lane offset) addressing
@@ -150,7 +200,8 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
     V8 f[3];
     f[0] = *reinterpret_cast<const V8*>(wb);
     f[1] = *reinterpret_cast<const V8*>(wb + 1024);
-    const float bcol = Bs[c * LBN + li];
+    const float bcol = to_f32<T>(bias_next);
+    if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
     if (stage_next >= 0) stage(stage_next);                // DMA issue behind the first fragment reads
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -180,6 +231,10 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
 
   // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 32 RT rows x 128 B
   auto epilogue = [&](int c) {
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 4)   // lab ablation: no epilogue at all (accumulators kept alive)
+    asm volatile("" :: "v"(acc0), "v"(acc1));
+    return;
+#endif
     const unsigned half = 64u * (c & 1);                   // which half of the 128-byte row
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -205,6 +260,9 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
     if (!(c & 1)) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS write -> read (other lanes' data)
     unsigned char* cw = cblk + (size_t)(c >> 1) * gstride;
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 2)   // lab ablation: no global stores
+    return;
+#endif
     if (block_full) {
 #pragma unroll
       for (int i = 0; i < Cfg::NSTORE; ++i)
@@ -234,22 +292,22 @@ __global__ __launch_bounds__(LTHREADS, 1) void linear_kres_kernel(const T* __res
   }
 }
 
-template <class T, int KS, int RT>
+template <class T, int KS, int RT, int NW>
 static void launch_linear_kres(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int planar, hipStream_t s) {
-  const int blocks = ceil_div(M, LinCfg<KS, RT>::ROWS);
+  const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
   if (gelu)
-    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A,
+    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A,
                        (const T*)W, (const T*)bias, (T*)C, M, N, planar);
   else
-    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT>), dim3(blocks), dim3(LTHREADS), 0, s, (const T*)A,
+    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A,
                        (const T*)W, (const T*)bias, (T*)C, M, N, planar);
 }
 
-template <int KS, int RT>
+template <int KS, int RT, int NW>
 static int linear_kres(const char* name, const void* A, const void* W, const void* bias, void* C, int M, int N,
                        int gelu, int out_layout, int dtype, void* stream) {
-  typedef LinCfg<KS, RT> Cfg;
+  typedef LinCfg<KS, RT, NW> Cfg;
   DSS_REQUIRE(A && W && bias && C, "%s: null pointer", name);
   DSS_REQUIRE(M > 0 && N > 0 && N % (2 * LBN) == 0 && N <= Cfg::MAXN, "%s: need M > 0, N %% %d == 0, N <= %d (M=%d N=%d)",
               name, 2 * LBN, Cfg::MAXN, M, N);
@@ -258,8 +316,8 @@ static int linear_kres(const char* name, const void* A, const void* W, const voi
   hipStream_t s = (hipStream_t)stream;
   const int planar = out_layout == DSS_PLANAR64;
   switch (dtype) {
-    case DSS_F16: launch_linear_kres<f16, KS, RT>(A, W, bias, C, M, N, gelu, planar, s); break;
-    case DSS_BF16: launch_linear_kres<bf16, KS, RT>(A, W, bias, C, M, N, gelu, planar, s); break;
+    case DSS_F16: launch_linear_kres<f16, KS, RT, NW>(A, W, bias, C, M, N, gelu, planar, s); break;
+    case DSS_BF16: launch_linear_kres<bf16, KS, RT, NW>(A, W, bias, C, M, N, gelu, planar, s); break;
     default: return fail(DSS_ERR_BAD_ARG, "%s: dtype must be DSS_F16 or DSS_BF16 (got %d)", name, dtype);
   }
   DSS_CHECK_LAUNCH(name);
@@ -270,10 +328,10 @@ static int linear_kres(const char* name, const void* A, const void* W, const voi
 
 extern "C" int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
-  return dss::linear_kres<24, 2>("dss_linear_k384", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
+  return dss::linear_kres<24, 2, 4>("dss_linear_k384", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
 }
 
 extern "C" int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
-  return dss::linear_kres<48, 1>("dss_linear_k768", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
+  return dss::linear_kres<48, 1, 8>("dss_linear_k768", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
 }
