@@ -31,6 +31,19 @@
 #include "common.h"
 #include "kres.h"
 
+// scripts/probes/linear_lab.hip includes this file with DSS_LIN_TIMELINE defined: wave 0 of every workgroup adds the shader
+// cycles it spends in the A prologue, the MFMA phases, the epilogues and the end-of-chunk wait + barrier to dss_lin_tl.
+#ifdef DSS_LIN_TIMELINE
+__device__ unsigned long long dss_lin_tl[8];
+#define DSS_TL_DECL unsigned long long tl_t = __builtin_readcyclecounter(), tl_acc[4] = {0, 0, 0, 0}; const unsigned long long tl_r0 = wall_clock64();
+#define DSS_TL_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); tl_acc[i] += n_ - tl_t; tl_t = n_; }
+#define DSS_TL_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&dss_lin_tl[i_], tl_acc[i_]); atomicAdd(&dss_lin_tl[4], 1ull); atomicAdd(&dss_lin_tl[5], wall_clock64() - tl_r0); }
+#else
+#define DSS_TL_DECL
+#define DSS_TL_MARK(i)
+#define DSS_TL_FLUSH
+#endif
+
 namespace dss {
 
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
@@ -75,6 +88,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   const int rloc = wave * Cfg::ROWS_WAVE;                  // this wave's first row inside the workgroup
   const bool block_full = mrem >= LBM;
 
+  DSS_TL_DECL
   // ---- this lane's RT token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ----------------------------
   // Through the wave's own LDS patch, 64 columns at a time: LDS-DMA pieces of 8 rows x 128 B (FULL lines of A, 8 lanes per
   // row; 16-byte chunk c of row r lands at position c ^ ((r >> 1) & 7): the swizzle is applied to the source address) and
@@ -197,9 +211,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   //      phase starts with a zero accumulator and no LDS round trip in front of the first MFMA.
   auto mfma_phase = [&](int c, int stage_next) {
     const unsigned char* wb = &Ws[c & 1][16 * lane];
-    V8 f[3];
-    f[0] = *reinterpret_cast<const V8*>(wb);
-    f[1] = *reinterpret_cast<const V8*>(wb + 1024);
+    constexpr int PF = 2;                                  // W fragments in flight ahead of the MFMAs (3: measured equal)
+    V8 f[PF + 1];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
     const float bcol = to_f32<T>(bias_next);
     if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
     if (stage_next >= 0) stage(stage_next);                // DMA issue behind the first fragment reads
@@ -208,14 +223,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < LKS; ++s) {
-      if (s + 2 < LKS) f[(s + 2) % 3] = *reinterpret_cast<const V8*>(wb + 1024 * (s + 2));
+      if (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
       if (RT == 2) {
-        acc0 = mfma32x32x16(f[s % 3], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
-        acc1 = mfma32x32x16(f[s % 3], a[RT - 1][s], acc1);
+        acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
+        acc1 = mfma32x32x16(f[s % (PF + 1)], a[RT - 1][s], acc1);
       } else if (s & 1) {
-        acc1 = mfma32x32x16(f[s % 3], a[0][s], acc1);
+        acc1 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc1);
       } else {
-        acc0 = mfma32x32x16(f[s % 3], a[0][s], acc0);
+        acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);
       }
     }
     V8 fb, a_one;
@@ -284,12 +299,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   stage(0);
   wait_vm();
   __syncthreads();
+  DSS_TL_MARK(0)
   for (int c = 0; c < nchunks; ++c) {
     mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
+    DSS_TL_MARK(1)
     epilogue(c);
+    DSS_TL_MARK(2)
     wait_dma(c);
     phase_barrier();
+    DSS_TL_MARK(3)
   }
+  DSS_TL_FLUSH
 }
 
 template <class T, int KS, int RT, int NW>
