@@ -521,10 +521,12 @@ def main():
     warm_imgs = host[: min(a.batch, host.shape[0])].to(dev)
     if warm_imgs.shape[0] < a.batch:
         warm_imgs = warm_imgs.repeat((a.batch + warm_imgs.shape[0] - 1) // warm_imgs.shape[0], 1, 1, 1)[: a.batch]
-    torch.cuda.synchronize()
-    t_h = time.perf_counter()
-    step(model, warm_imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
-    host_only_ms = (time.perf_counter() - t_h) * 1e3
+    host_only_ms = float("inf")
+    for _ in range(2):    # the first call may still grow the allocator's pools (hipMalloc is synchronous): take the second
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        step(model, warm_imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+        host_only_ms = min(host_only_ms, (time.perf_counter() - t_h) * 1e3)
     del warm_imgs
     torch.cuda.synchronize()
 
