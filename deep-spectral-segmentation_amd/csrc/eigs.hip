@@ -5,10 +5,11 @@
 
 namespace dss {
 
-static constexpr int EIGS_THREADS = 1024;  // upper bound of the launch (register budget: 128 VGPRs)
+static constexpr int EIGS_THREADS = 512;          // launch size: 8 waves per image
+static constexpr int EIGS_WAVES_PER_SIMD = 4;    // 128 registers per lane: two images per CU
 
 template <class WE>
-__global__ __launch_bounds__(EIGS_THREADS) void laplacian_eigs_kernel(const WE* __restrict__ W, EigsParams P,
+__global__ __launch_bounds__(EIGS_THREADS, EIGS_WAVES_PER_SIMD) void laplacian_eigs_kernel(const WE* __restrict__ W, EigsParams P,
                                                                       float* gws, size_t gws_stride,
                                                                       float* eigenvalues, float* eigenvectors,
                                                                       int32_t* info) {
@@ -82,7 +83,11 @@ static int symmetric_eigs(const WE* W, int B, int N, int K, int mode, float* eig
     return fail(DSS_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu): %s", L.total, hipGetErrorString(e));
   // 512-thread workgroups let two images share a CU: the serial Rayleigh-Ritz / restart phases of one overlap the W
   // streaming of the other (measured against one 16-wave workgroup per CU in round 1).
+#ifdef DSS_EIGS_THREADS   // lab builds (scripts/debug/eigs_lab.py)
+  const int threads = DSS_EIGS_THREADS;
+#else
   const int threads = 512;
+#endif
   hipLaunchKernelGGL(laplacian_eigs_kernel<WE>, dim3(B), dim3(threads), L.total, (hipStream_t)stream, W, P,
                      (float*)workspace, per_img, eigenvalues, eigenvectors, info);
   DSS_CHECK_LAUNCH("laplacian_eigs");
@@ -111,6 +116,23 @@ extern "C" int dss_symmetric_eigs(const float* W, int B, int N, int K, int mode,
   return dss::symmetric_eigs<float>(W, B, N, K, mode, eigenvalues, eigenvectors, info, ncv, tol, max_restarts,
                                     workspace, workspace_bytes, stream);
 }
+
+#ifdef DSS_EIGS_TIMELINE
+extern "C" int dss_eigs_timeline(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(dss_eigs_tl), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dss_eigs_tl), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
+#ifdef DSS_EIGS_RHO_DEBUG
+extern "C" int dss_eigs_rho_buffer(float* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(dss_eigs_rho_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int dss_sign_rule(float* eigenvectors, int rows, int N, void* stream) {
   DSS_REQUIRE(eigenvectors, "dss_sign_rule: null pointer");

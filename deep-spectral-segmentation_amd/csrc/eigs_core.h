@@ -38,6 +38,10 @@
 #define DSS_SYNC() ((void)0)
 #define DSS_WAVE_SUM(x) (x)
 #define DSS_WAVE_MAX(x) (x)
+#define DSS_LDS_ADD(p, v) (*(p) += (v))
+#define DSS_WAVE_SYNC() ((void)0)
+#define DSS_RSQRT64(x) (1.0 / sqrt(x))
+#define DSS_SETPRIO(p) ((void)0)
 #else
 #define DSS_DEV __device__ __forceinline__
 #define DSS_HD __host__ __device__
@@ -50,11 +54,53 @@
 #define DSS_SYNC() __syncthreads()
 #define DSS_WAVE_SUM(x) ::dss::wave_sum(x)
 #define DSS_WAVE_MAX(x) ::dss::wave_max(x)
+#define DSS_LDS_ADD(p, v) atomicAdd((p), (v))
+// one wave working alone on LDS: its ds_* instructions execute in program order, so only the COMPILER has to be kept
+// from moving accesses of different lanes across the point
+#define DSS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define DSS_RSQRT64(x) ::dss::rsqrt64(x)
+#define DSS_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
+// Lab build (-DDSS_EIGS_TIMELINE, scripts/debug/eigs_lab.py): thread 0 of every workgroup adds the shader-clock cycles
+// the workgroup spends in each phase of the solve to dss_eigs_tl[phase] (slots 8..: Rayleigh-Ritz calls, Jacobi sweeps).
+#if defined(DSS_EIGS_TIMELINE) && !defined(DSS_HOST_EMUL)
+__device__ unsigned long long dss_eigs_tl[16];
+#define DSS_ETL_DECL unsigned long long etl_t = __builtin_readcyclecounter(), etl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DSS_ETL_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); etl_acc[i] += n_ - etl_t; etl_t = n_; }
+#define DSS_ETL_COUNT1(i) atomicAdd(&dss_eigs_tl[i], 1ull);
+#define DSS_ETL_FLUSH if (DSS_TID == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&dss_eigs_tl[i_], etl_acc[i_]); }
+#define DSS_ETL_WAVE_T0 const unsigned long long etl_w0 = __builtin_readcyclecounter();
+#define DSS_ETL_WAVE_ADD(i) if (DSS_LANE == 0) atomicAdd(&dss_eigs_tl[i], __builtin_readcyclecounter() - etl_w0);
+#else
+#define DSS_ETL_DECL
+#define DSS_ETL_MARK(i)
+#define DSS_ETL_COUNT1(i)
+#define DSS_ETL_FLUSH
+#define DSS_ETL_WAVE_T0
+#define DSS_ETL_WAVE_ADD(i)
+#endif
+
+#if defined(DSS_EIGS_RHO_DEBUG) && !defined(DSS_HOST_EMUL)
+__device__ float* dss_eigs_rho_buf;   // [images, 64]: worst residual ratio seen by the check of state j
+#define DSS_EIGS_RHO_TRACE(j, rho) if (DSS_TID == 0 && dss_eigs_rho_buf) dss_eigs_rho_buf[(size_t)blockIdx.x * 64 + (j)] = (rho);
+#else
+#define DSS_EIGS_RHO_TRACE(j, rho)
 #endif
 
 namespace dss {
 
 static constexpr int EIGS_MAX_NCV = 64;
+// Convergence checks: after a check whose worst residual is still > SKIP1 (SKIP2) times its bar, the next one (two)
+// steps are not checked.
+#ifndef DSS_EIGS_SKIP1
+#define DSS_EIGS_SKIP1 30.f
+#endif
+#ifndef DSS_EIGS_SKIP2
+#define DSS_EIGS_SKIP2 1000.f
+#endif
+static constexpr float EIGS_SKIP1_RATIO = DSS_EIGS_SKIP1, EIGS_SKIP2_RATIO = DSS_EIGS_SKIP2;
 
 // Operator / selection modes (one Lanczos, three problems of the reference's _extract_eig):
 //   EIGS_NORMALIZED_LAPLACIAN  S = D^-1/2 W D^-1/2, K largest theta; lambda = 1 - theta, v = D^-1/2 u
@@ -115,7 +161,33 @@ struct EigsSmall {  // lives in LDS at off_small (<= 6144 B)
   float red[64];                // cross-wave reduction scratch
   double jc[EIGS_MAX_NCV / 2], js[EIGS_MAX_NCV / 2];  // Jacobi rotations of the current round
   int jp[EIGS_MAX_NCV / 2], jq[EIGS_MAX_NCV / 2];
-  int flag;
+  int flag;                     // a rotation was applied in the current Jacobi sweep
+  int big;                      // ... and at least one of them was not yet negligible (see jacobi_eig)
+  int nbad;                     // verdict of the convergence check that ran beside the W stream
+  float rho;                    // ... and its worst residual / tolerance ratio over the K wanted pairs
+};
+
+#ifndef DSS_HOST_EMUL
+// 1 / sqrt(x) for x in [1, 2] to fp64 rounding: v_rsq_f64 seed + two Newton steps (no IEEE divide / sqrt expansion)
+DSS_DEV double rsqrt64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+#endif
+
+// Who executes a cooperative routine: the whole workgroup, or ONE wave on its own (the Rayleigh-Ritz check that runs
+// beside the other waves' W stream, see eigs_one_image).
+struct BlockScope {
+  static DSS_DEV int tid() { return DSS_TID; }
+  static DSS_DEV int nt() { return DSS_NT; }
+  static DSS_DEV void sync() { DSS_SYNC(); }
+};
+struct WaveScope {
+  static DSS_DEV int tid() { return DSS_LANE; }
+  static DSS_DEV int nt() { return DSS_LANES; }
+  static DSS_DEV void sync() { DSS_WAVE_SYNC(); }
 };
 
 DSS_DEV float block_sum(float v, EigsSmall* sm) {
@@ -168,13 +240,23 @@ template <class WE> struct WElem;
 template <> struct WElem<float> { static constexpr float scale = 1.0f; };
 template <> struct WElem<uint16_t> { static constexpr float scale = 65535.0f; };
 
-template <class WE>
+#ifdef DSS_EIGS_PLAIN_LOADS   // lab: W through the default cache policy instead of the streaming (nt) one
+#define DSS_W_LOAD(p) (*(p))
+#else
+#define DSS_W_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+struct NoSideJob { DSS_DEV void operator()() const {} };
+
+// `side`: a job for ONE wave that does not touch xs / ws (the convergence check of the previous Lanczos state).  When
+// `side_on`, the last wave of the workgroup runs it while the other waves share the tiles.
+template <class WE, class Side = NoSideJob>
 DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* xs, float* ws, const float* dis,
-                        bool scale) {
+                        bool scale, bool side_on = false, const Side& side = Side()) {
   const int nt = ld / WT;
   for (int e = DSS_TID; e < ld; e += DSS_NT) ws[e] = 0.f;
   DSS_SYNC();
 #ifdef DSS_HOST_EMUL
+  if (side_on) side();
   for (int I = 0; I < nt; ++I)
     for (int J = I; J < nt; ++J) {
       const WE* A = Wp + (size_t)(wsym_row_start(I, nt) + (J - I)) * WT * WT;
@@ -195,20 +277,27 @@ DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* x
   const int g = lane >> 4, q = lane & 15;         // lane -> rows 4k + g (k = 0..15), columns 4q .. 4q+3
   const int ntiles = wsym_tiles(nt);
   int I = 0, row_start = 0;                        // tile row of the current tile index (advanced incrementally)
-  for (int t = DSS_WAVE; t < ntiles; t += DSS_NWAVES) {
+  const bool split = side_on && DSS_NWAVES > 1;
+  const int stream_waves = split ? DSS_NWAVES - 1 : DSS_NWAVES;
+  DSS_ETL_WAVE_T0
+  if (side_on && (!split || DSS_WAVE == stream_waves)) {
+    side();
+    DSS_ETL_WAVE_ADD(11)   // cycles of the check (its wave)
+  }
+  for (int t = (split && DSS_WAVE == stream_waves) ? ntiles : DSS_WAVE; t < ntiles; t += stream_waves) {
     while (t >= row_start + (nt - I)) { row_start += nt - I; ++I; }
     const int J = I + (t - row_start);
     f32x4 a[16];
     if constexpr (sizeof(WE) == 4) {
       const f32x4* A4 = reinterpret_cast<const f32x4*>(Wp + (size_t)t * WT * WT);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = __builtin_nontemporal_load(A4 + k * 64 + lane);
+      for (int k = 0; k < 16; ++k) a[k] = DSS_W_LOAD(A4 + k * 64 + lane);
     } else {  // 4 x u16 per lane per row group: same (row, column) ownership as the float path, 8-byte loads
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       const u32x2* A2 = reinterpret_cast<const u32x2*>(Wp + (size_t)t * WT * WT);
       u32x2 raw[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) raw[k] = __builtin_nontemporal_load(A2 + k * 64 + lane);
+      for (int k = 0; k < 16; ++k) raw[k] = DSS_W_LOAD(A2 + k * 64 + lane);
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         a[k][0] = (float)(raw[k][0] & 0xffffu);
@@ -278,97 +367,194 @@ DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* x
       atomicAdd(&ws[J * WT + 4 * q + 2 * (g & 1) + (g >> 1)], c0);
     }
   }
+  if (DSS_WAVE == 0) { DSS_ETL_WAVE_ADD(side_on ? 12 : 10) }   // tile loop of wave 0: with / without a check beside it
 #endif
   DSS_SYNC();
+  if (DSS_WAVE == 0) { DSS_ETL_WAVE_ADD(side_on ? 14 : 13) }     // ... including the wait for the slowest wave
   if (scale)
     for (int e = DSS_TID; e < N; e += DSS_NT) ws[e] *= dis[e];
   DSS_SYNC();
 }
 
-// coef[i] = V[i] . ws  for i in [0, nvec)  (wave per basis vector, lanes strided over elements)
-DSS_DEV void basis_dots(const float* V, int ldv, int nvec, const float* ws, int N, float* coef) {
-  for (int i = DSS_WAVE; i < nvec; i += DSS_NWAVES) {
-    const float* v = V + (size_t)i * ldv;
-    float acc = 0.f;
-    for (int e = DSS_LANE; e < N; e += DSS_LANES) acc += v[e] * ws[e];
-    acc = DSS_WAVE_SUM(acc);
-    if (DSS_LANE == 0) coef[i] = acc;
+#ifndef DSS_HOST_EMUL
+// Sum R values (a power of two <= 32) over the 64 lanes with R + 4 exchanges instead of 6 R: a halving butterfly (a lane
+// keeps half of its values and adds the partner's other half) leaves value k complete in the lanes k * (64 / R) ...,
+// which a last plain butterfly over the low lane bits makes identical.  Returns the value of index lane / (64 / R).
+template <int R>
+DSS_DEV float wave_sum_many(float (&p)[R], int lane) {
+  int mask = 32;
+#pragma unroll
+  for (int n = R / 2; n >= 1; n >>= 1, mask >>= 1) {
+    const bool up = (lane & mask) != 0;
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      const float send = up ? p[k] : p[k + n];
+      const float keep = up ? p[k + n] : p[k];
+      p[k] = keep + __shfl_xor(send, mask, 64);
+    }
   }
+#pragma unroll
+  for (; mask >= 1; mask >>= 1) p[0] += __shfl_xor(p[0], mask, 64);
+  return p[0];
+}
+#endif
+
+// Gram-Schmidt against the L2-resident basis.  Threads own ELEMENTS (e, e + NT), and a round handles 8 basis vectors:
+// 16 independent coalesced loads per thread are in flight before the first use (a loop over the elements of one
+// vector, a wave per vector, costs one L2 round trip per 64 elements: 14 in a row at N = 900).
+//
+// coef[i] = V[i] . ws  for i in [0, nvec).  Barriers inside; coef is complete on return.
+DSS_DEV void basis_dots(const float* V, int ldv, int nvec, const float* ws, int N, float* coef) {
+  for (int i = DSS_TID; i < nvec; i += DSS_NT) coef[i] = 0.f;
+  DSS_SYNC();
+  for (int i0 = 0; i0 < nvec; i0 += 8) {
+    float part[8];
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) part[ii] = 0.f;
+    for (int e = DSS_TID; e < N; e += 2 * DSS_NT) {
+      const bool two = e + DSS_NT < N;
+      const int e1 = two ? e + DSS_NT : e;
+      const float w0 = ws[e], w1 = two ? ws[e1] : 0.f;
+      float v0[8], v1[8];
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) {
+        const float* v = V + (size_t)(i0 + ii < nvec ? i0 + ii : nvec - 1) * ldv;   // clamped: no divergent loads
+        v0[ii] = v[e];
+        v1[ii] = v[e1];
+      }
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) part[ii] += v0[ii] * w0 + v1[ii] * w1;
+    }
+#ifdef DSS_HOST_EMUL
+    for (int ii = 0; ii < 8; ++ii)
+      if (i0 + ii < nvec) coef[i0 + ii] += part[ii];
+#else
+    const float t = wave_sum_many<8>(part, DSS_LANE);
+    if ((DSS_LANE & 7) == 0 && i0 + (DSS_LANE >> 3) < nvec) DSS_LDS_ADD(&coef[i0 + (DSS_LANE >> 3)], t);
+#endif
+  }
+  DSS_SYNC();
 }
 
-// ws[e] -= sum_i coef[i] * V[i][e]
-DSS_DEV void basis_axpy(const float* V, int ldv, int nvec, float* ws, int N, const float* coef) {
-  for (int e = DSS_TID; e < N; e += DSS_NT) {
-    float acc = ws[e];
-    for (int i = 0; i < nvec; ++i) acc -= coef[i] * V[(size_t)i * ldv + e];
-    ws[e] = acc;
+// ws[e] -= sum_i coef[i] * V[i][e]; returns this thread's share of |ws|^2 after the update
+DSS_DEV float basis_axpy(const float* V, int ldv, int nvec, float* ws, int N, const float* coef) {
+  float n2 = 0.f;
+  for (int e = DSS_TID; e < N; e += 2 * DSS_NT) {
+    const bool two = e + DSS_NT < N;
+    const int e1 = two ? e + DSS_NT : e;
+    float a0 = ws[e], a1 = ws[e1];
+    for (int i0 = 0; i0 < nvec; i0 += 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) {
+        const float* v = V + (size_t)(i0 + ii < nvec ? i0 + ii : nvec - 1) * ldv;
+        v0[ii] = v[e];
+        v1[ii] = v[e1];
+      }
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) {
+        const float c = i0 + ii < nvec ? coef[i0 + ii] : 0.f;
+        a0 -= c * v0[ii];
+        a1 -= c * v1[ii];
+      }
+    }
+    ws[e] = a0;
+    n2 += a0 * a0;
+    if (two) { ws[e1] = a1; n2 += a1 * a1; }
   }
+  return n2;
 }
 
 // Symmetric eigen-decomposition of the (m x m) projected matrix by the classical two-sided Jacobi method with
 // a parallel (round-robin) ordering, fp64, entirely in LDS.  A round rotates M/2 DISJOINT index pairs at once:
 //   1. one thread per pair: (c, s) from a_pp, a_qq, a_pq                       - no reductions at all
-//   2. one thread per (row, pair): columns p,q of A and of the accumulated V   (A <- A J, V <- V J)
-//   3. one thread per (pair, column): rows p,q of A                            (A <- J^T A)
+//   2. one thread per (pair, pair): a 2x2 block of A <- J^T A J and two rows of two columns of V <- V J
 // with a barrier after each step.  A and Vr are column-major with leading dimension m (A is symmetric).
 // On exit theta[c] = A[c][c], Vr[:, c] = eigenvector, perm = ranks (descending theta).
+template <class S>
 DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm, bool by_magnitude) {
   const int M = (m + 1) & ~1, np = M / 2;
+  const float inv_np = 1.0f / (float)np;
   for (int sweep = 0; sweep < 30; ++sweep) {
-    if (DSS_TID == 0) sm->flag = 0;
-    DSS_SYNC();
+    if (S::tid() == 0) { sm->flag = 0; sm->big = 0; }
+    S::sync();
     for (int round = 0; round < M - 1; ++round) {
-      for (int k = DSS_TID; k < np; k += DSS_NT) {
+      // 1. rotation of every pair from three entries.  Only ORTHOGONALITY needs fp64 (c^2 + s^2 = 1): an angle that is
+      //    off by 1e-7 relative still shrinks a_pq by that factor, so tan comes from f32 arithmetic and the long fp64
+      //    divide / square-root chains (the latency of a round, with <= 32 lanes busy) reduce to one reciprocal root.
+      for (int k = S::tid(); k < np; k += S::nt()) {
         int p, q;
         if (k == 0) { p = M - 1; q = round; }
-        else { p = (round + k) % (M - 1); q = (round - k + (M - 1)) % (M - 1); }
+        else {
+          p = round + k; if (p >= M - 1) p -= M - 1;
+          q = round - k; if (q < 0) q += M - 1;
+        }
         if (p > q) { const int t = p; p = q; q = t; }
         double c = 1.0, sn = 0.0;
-        if (q < m) {
+        if (q < m) {   // q == m: the dummy index of an odd m - identity
           const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q], apq = A[(size_t)q * m + p];
-          if (fabs(apq) > 1e-17 + 1e-15 * sqrt(fabs(app * aqq))) {
-            const double zeta = (aqq - app) / (2.0 * apq);
-            const double t = (zeta >= 0. ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            c = 1.0 / sqrt(1.0 + t * t);
+          const double a2 = apq * apq, d2 = fabs(app * aqq);
+          if (a2 > 1e-34 + 1e-20 * d2) sm->big = 1;  // |a_pq| > 1e-10 sqrt|a_pp a_qq|; benign race: every writer stores 1
+          if (a2 > 1e-34 + 1e-30 * d2) {             // |a_pq| > 1e-15 sqrt|a_pp a_qq|
+            const float h = (float)(0.5 * (aqq - app)), bq = (float)apq;
+            const float tf = bq / (fabsf(h) + sqrtf(h * h + bq * bq));   // tan of the smaller rotation angle
+            const double t = (double)(h < 0.f ? -tf : tf);
+            c = DSS_RSQRT64(1.0 + t * t);
             sn = c * t;
             sm->flag = 1;  // benign race: every writer stores 1
           }
-        } else {
-          q = p;  // dummy pair (odd m): identity
         }
         sm->jp[k] = p; sm->jq[k] = q; sm->jc[k] = c; sm->js[k] = sn;
       }
-      DSS_SYNC();
-      for (int idx = DSS_TID; idx < np * m; idx += DSS_NT) {  // columns p,q of A and V, one row each
-        const int k = idx / m, r = idx - k * m;
-        const int p = sm->jp[k], q = sm->jq[k];
-        if (p == q) continue;
-        const double c = sm->jc[k], sn = sm->js[k];
-        const double ap = A[(size_t)p * m + r], aq = A[(size_t)q * m + r];
-        A[(size_t)p * m + r] = c * ap - sn * aq;
-        A[(size_t)q * m + r] = sn * ap + c * aq;
-        const double vp = Vr[(size_t)p * m + r], vq = Vr[(size_t)q * m + r];
-        Vr[(size_t)p * m + r] = c * vp - sn * vq;
-        Vr[(size_t)q * m + r] = sn * vp + c * vq;
+      S::sync();
+      // 2. A <- J^T A J by 2x2 blocks (row pair k1 x column pair k2: four entries in, four out, nobody else touches
+      //    them) and V <- V J (row pair r = 2 k1, 2 k1 + 1 x column pair k2) in the same pass: one barrier per round.
+      for (int idx = S::tid(); idx < np * np; idx += S::nt()) {
+        const int k1 = (int)(((float)idx + 0.5f) * inv_np), k2 = idx - k1 * np;
+        const int p2 = sm->jp[k2], q2 = sm->jq[k2];
+        const double c2 = sm->jc[k2], s2 = sm->js[k2];
+        const bool hq2 = q2 < m;
+        {
+          const int p1 = sm->jp[k1], q1 = sm->jq[k1];
+          const double c1 = sm->jc[k1], s1 = sm->js[k1];
+          const bool hq1 = q1 < m;
+          const double app = A[(size_t)p2 * m + p1];
+          const double apq = hq2 ? A[(size_t)q2 * m + p1] : 0.;
+          const double aqp = hq1 ? A[(size_t)p2 * m + q1] : 0.;
+          const double aqq = hq1 && hq2 ? A[(size_t)q2 * m + q1] : 0.;
+          // columns (J on the right), then rows (J^T on the left)
+          const double bpp = c2 * app - s2 * apq, bpq = s2 * app + c2 * apq;
+          const double bqp = c2 * aqp - s2 * aqq, bqq = s2 * aqp + c2 * aqq;
+          A[(size_t)p2 * m + p1] = c1 * bpp - s1 * bqp;
+          if (hq2) A[(size_t)q2 * m + p1] = c1 * bpq - s1 * bqq;
+          if (hq1) A[(size_t)p2 * m + q1] = s1 * bpp + c1 * bqp;
+          if (hq1 && hq2) A[(size_t)q2 * m + q1] = s1 * bpq + c1 * bqq;
+        }
+        if (hq2) {
+          const int r0 = 2 * k1, r1 = 2 * k1 + 1;
+          const double v0p = Vr[(size_t)p2 * m + r0], v0q = Vr[(size_t)q2 * m + r0];
+          Vr[(size_t)p2 * m + r0] = c2 * v0p - s2 * v0q;
+          Vr[(size_t)q2 * m + r0] = s2 * v0p + c2 * v0q;
+          if (r1 < m) {
+            const double v1p = Vr[(size_t)p2 * m + r1], v1q = Vr[(size_t)q2 * m + r1];
+            Vr[(size_t)p2 * m + r1] = c2 * v1p - s2 * v1q;
+            Vr[(size_t)q2 * m + r1] = s2 * v1p + c2 * v1q;
+          }
+        }
       }
-      DSS_SYNC();
-      for (int idx = DSS_TID; idx < np * m; idx += DSS_NT) {  // rows p,q of A, one column each
-        const int k = idx / m, col = idx - k * m;
-        const int p = sm->jp[k], q = sm->jq[k];
-        if (p == q) continue;
-        const double c = sm->jc[k], sn = sm->js[k];
-        const double ap = A[(size_t)col * m + p], aq = A[(size_t)col * m + q];
-        A[(size_t)col * m + p] = c * ap - sn * aq;
-        A[(size_t)col * m + q] = sn * ap + c * aq;
-      }
-      DSS_SYNC();
+      S::sync();
     }
-    if (sm->flag == 0) break;  // a full sweep without a rotation: converged (uniform: read after the barrier)
-    DSS_SYNC();
+    if (S::tid() == 0) { DSS_ETL_COUNT1(9) }
+    // Converged after a sweep without a rotation - or one whose rotations all had |a_pq| <= 1e-10 sqrt|a_pp a_qq|: the
+    // off-diagonal left behind is second order in that (<= 1e-20 / gap), so the confirming sweep would not rotate
+    // anything that matters at the 2e-6 residual test.  (uniform: read after the barrier)
+    if (sm->flag == 0 || sm->big == 0) break;
+    S::sync();
   }
-  for (int c = DSS_TID; c < m; c += DSS_NT) sm->theta[c] = A[(size_t)c * m + c];
-  DSS_SYNC();
-  for (int c = DSS_TID; c < m; c += DSS_NT) {
+  if (S::tid() == 0) { DSS_ETL_COUNT1(8) }
+  for (int c = S::tid(); c < m; c += S::nt()) sm->theta[c] = A[(size_t)c * m + c];
+  S::sync();
+  for (int c = S::tid(); c < m; c += S::nt()) {
     int rank = 0;
     const double tc = by_magnitude ? fabs(sm->theta[c]) : sm->theta[c];
     for (int j = 0; j < m; ++j) {
@@ -377,15 +563,16 @@ DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm, bool by_mag
     }
     sm->perm[rank] = c;
   }
-  DSS_SYNC();
+  S::sync();
 }
 
 // Rayleigh-Ritz on the projected matrix T (m x m): diagonal alpha, arrow column l (after a restart),
 // off-diagonal beta[j] = T[j][j+1] for j >= l.  Returns the number of the K wanted Ritz pairs whose residual
 // |beta_last * z_{m-1,i}| exceeds tol * max(|theta_i|, 1e-3).  Leaves Vr / sm->theta / sm->perm set.
+template <class S>
 DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double beta_last, float tol, EigsSmall* sm,
-                          bool by_magnitude) {
-  for (int idx = DSS_TID; idx < m * m; idx += DSS_NT) {
+                          bool by_magnitude, float* worst_ratio = nullptr) {
+  for (int idx = S::tid(); idx < m * m; idx += S::nt()) {
     const int c = idx / m, r = idx - c * m;
     double t = 0.;
     if (r == c) t = sm->alpha[r];
@@ -397,18 +584,22 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
     A[idx] = t;
     Vr[idx] = r == c ? 1.0 : 0.0;
   }
-  DSS_SYNC();
-  jacobi_eig(A, Vr, m, sm, by_magnitude);
+  S::sync();
+  jacobi_eig<S>(A, Vr, m, sm, by_magnitude);
   double tmax = 0.;  // tolerance floor relative to the largest Ritz value in magnitude (1 for the normalised Laplacian)
   for (int c = 0; c < m; ++c) tmax = fabs(sm->theta[c]) > tmax ? fabs(sm->theta[c]) : tmax;
   int nbad = 0;
+  double worst = 0.;
   for (int i = 0; i < K; ++i) {
-    if (i >= m) { ++nbad; continue; }
+    if (i >= m) { ++nbad; worst = 1e30; continue; }
     const int c = sm->perm[i];
     const double res = fabs(beta_last * Vr[(size_t)c * m + (m - 1)]);
     const double th = fabs(sm->theta[c]);
-    if (res > (double)tol * (th > 1e-3 * tmax ? th : 1e-3 * tmax)) ++nbad;
+    const double bar = (double)tol * (th > 1e-3 * tmax ? th : 1e-3 * tmax);
+    if (res > bar) ++nbad;
+    if (res > worst * bar) worst = res / bar;
   }
+  if (worst_ratio) *worst_ratio = (float)(worst < 1e30 ? worst : 1e30);
   return nbad;
 }
 
@@ -432,6 +623,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
   float* Vb = gws + (size_t)(mmax + 1) * ldv;
   float* dis = gws + (size_t)2 * (mmax + 1) * ldv;
   int passes = 0;
+  DSS_ETL_DECL
 
   // ---- degree: d = W 1 ; clamp (extract_utils.py:218) ; dis = d^-1/2 (normalised) or d itself (plain Laplacian) ----
   const int mode = P.mode;
@@ -456,6 +648,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
     for (int e = DSS_TID; e < N; e += DSS_NT) Va[e] = ws[e] * inv;
   }
   DSS_SYNC();  // Va[0], dis visible to the block (same-workgroup global writes + barrier)
+  DSS_ETL_MARK(0)
 
   int l = 0;          // kept Ritz vectors (0 on the first cycle)
   int m = mmax;       // effective Krylov dimension of this cycle (shrinks on breakdown)
@@ -465,35 +658,51 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
   for (;; ++restart) {
     // ---- extend the Krylov basis from l to m --------------------------------------------------------
     bool breakdown = false, early = false;
+    int next_check = 0;
     for (int j = l; j < mmax; ++j) {
       const float* vj = Va + (size_t)j * ldv;
-      if (mode == EIGS_NORMALIZED_LAPLACIAN) {
-        for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? dis[e] * vj[e] : 0.0f;
+      // Convergence check of the CURRENT state (j basis vectors, T_j, beta_last = beta_{j-1}) by the last wave, beside
+      // the W stream of step j (the Jacobi sweeps are latency-bound and need no bandwidth).  A converged image is
+      // detected one pass late - that pass is discarded - instead of stalling every step of every image.
+      const bool check = j >= K + 3 && j > l + 1 && j >= next_check;
+      const auto side = [&]() {
+        float rho;
+        DSS_SETPRIO(3);   // a chain of dependent instructions sharing its SIMD with three streaming waves: issue it first
+        const int nb = rayleigh_ritz<WaveScope>(A, Vr, j, l, K, beta_last, P.tol, sm, by_mag, &rho);
+        DSS_SETPRIO(0);
+        if (DSS_LANE == 0) { sm->nbad = nb; sm->rho = rho; }
+      };
+      {
+        const bool nl = mode == EIGS_NORMALIZED_LAPLACIAN;
+        for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? (nl ? dis[e] * vj[e] : vj[e]) : 0.0f;
         DSS_SYNC();
-        matvec_sym(W, N, ld, xs, ws, dis, true);              // w = D^-1/2 W D^-1/2 v
-      } else {
-        for (int e = DSS_TID; e < ld; e += DSS_NT) xs[e] = e < N ? vj[e] : 0.0f;
-        DSS_SYNC();
-        matvec_sym(W, N, ld, xs, ws, nullptr, false);         // w = W v
-        if (mode == EIGS_LAPLACIAN) {                         // w = W v - D v = -(D - W) v
-          for (int e = DSS_TID; e < N; e += DSS_NT) ws[e] -= dis[e] * vj[e];
-          DSS_SYNC();
-        }
+        matvec_sym(W, N, ld, xs, ws, dis, nl, check, side);     // w = D^-1/2 W D^-1/2 v   or   w = W v
       }
       ++passes;
+      if (check) {   // residuals of a Lanczos process fall by a bounded factor per step: far from the bar, skip checks
+        const float rho = sm->rho;
+        next_check = j + 1 + (rho > EIGS_SKIP2_RATIO ? 2 : (rho > EIGS_SKIP1_RATIO ? 1 : 0));
+        DSS_EIGS_RHO_TRACE(j, rho)
+      }
+      if (check && sm->nbad == 0) {   // Vr / theta / perm describe T_j: finish from the j-vector basis
+        m = j;
+        early = true;
+        DSS_ETL_MARK(1)
+        break;
+      }
+      if (mode == EIGS_LAPLACIAN) {                             // w = W v - D v = -(D - W) v
+        for (int e = DSS_TID; e < N; e += DSS_NT) ws[e] -= dis[e] * vj[e];
+        DSS_SYNC();
+      }
+      DSS_ETL_MARK(1)
       // classical Gram-Schmidt, two passes (full reorthogonalisation against V[0..j])
       basis_dots(Va, ldv, j + 1, ws, N, sm->coef);
-      DSS_SYNC();
       double alpha = (double)sm->coef[j];
       basis_axpy(Va, ldv, j + 1, ws, N, sm->coef);
       DSS_SYNC();
       basis_dots(Va, ldv, j + 1, ws, N, sm->coef);
-      DSS_SYNC();
       alpha += (double)sm->coef[j];
-      basis_axpy(Va, ldv, j + 1, ws, N, sm->coef);
-      DSS_SYNC();
-      float b2 = 0.f;
-      for (int e = DSS_TID; e < N; e += DSS_NT) b2 += ws[e] * ws[e];
+      float b2 = basis_axpy(Va, ldv, j + 1, ws, N, sm->coef);   // every thread re-reads only its own elements below
       b2 = block_sum(b2, sm);
       const float beta = sqrtf(b2);
       if (DSS_TID == 0) { sm->alpha[j] = alpha; sm->beta[j] = (double)beta; }
@@ -512,15 +721,12 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
       }
       m = j + 1;
       DSS_SYNC();
-      // mid-cycle convergence check every 2 steps: a converged image stops streaming W at once
-      if (m < mmax && m >= K + 3 && m > l + 1 && ((m - l) & 1) == 0) {
-        if (rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm, by_mag) == 0) { early = true; break; }
-        DSS_SYNC();
-      }
+      DSS_ETL_MARK(2)
     }
     // ---- Rayleigh-Ritz on the full basis (skipped when a mid-cycle check already converged) -----------------
     int nbad = 0;
-    if (!early) nbad = rayleigh_ritz(A, Vr, m, l, K, beta_last, P.tol, sm, by_mag);
+    if (!early) nbad = rayleigh_ritz<BlockScope>(A, Vr, m, l, K, beta_last, P.tol, sm, by_mag);
+    DSS_ETL_MARK(4)
     converged = (nbad == 0);
     if (converged || breakdown || restart >= P.max_restarts) break;
     // ---- thick restart: keep the best `keep` Ritz vectors -----------------------------------------------
@@ -559,6 +765,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
     { float* t = Va; Va = Vb; Vb = t; }
     l = keep;
     DSS_SYNC();
+    DSS_ETL_MARK(5)
   }
 
   // ---- Ritz vectors -> generalized eigenvectors v = D^-1/2 u, sign rule, eigenvalues ----------------------
@@ -591,6 +798,8 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
     eigenvalues[i] = (float)(mode == EIGS_NORMALIZED_LAPLACIAN ? 1.0 - th : (mode == EIGS_LAPLACIAN ? -th : th));
   }
   if (DSS_TID == 0) *info = converged ? passes : -passes;
+  DSS_ETL_MARK(6)
+  DSS_ETL_FLUSH
 }
 
 }  // namespace dss

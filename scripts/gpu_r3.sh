@@ -28,6 +28,13 @@ for STAGE in "$@"; do
         pmc_pass wait_v$V SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE -- $REPO_DIR/scripts/probes/attn_lab 290 901 6 1 $V 2
         pmc_pass l2_v$V TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -- $REPO_DIR/scripts/probes/attn_lab 290 901 6 1 $V 2
       done;;
+    eigs_lab)   # product first (reference results), then every lab build in LAB_LIBS (scripts/build_lablib.sh tags)
+      rm -f gpurun_out/eigs_lab.log
+      timeout 300 python scripts/debug/eigs_lab.py --tag product --save /tmp/eigs_ref.npz ${EIGS_LAB_ARGS:-} 2>&1 | tail -1 >> gpurun_out/eigs_lab.log
+      for T in ${LAB_LIBS:-}; do
+        DSS_HIP_LIBRARY=$REPO_DIR/scripts/lablib/libdss_hip_$T.so timeout 300 python scripts/debug/eigs_lab.py --tag $T --ref /tmp/eigs_ref.npz ${EIGS_LAB_ARGS:-} 2>&1 | tail -1 >> gpurun_out/eigs_lab.log
+      done
+      cat gpurun_out/eigs_lab.log;;
     host_enqueue) timeout 600 python scripts/debug/host_enqueue.py > gpurun_out/host_enqueue.log 2>&1; echo "host_enqueue exit $?"; cat gpurun_out/host_enqueue.log;;
     tests) timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -x 2>&1 | tail -80 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
     tests_all) timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
