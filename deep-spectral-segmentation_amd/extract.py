@@ -57,6 +57,46 @@ _DTYPES = {"float16": torch.float16, "fp16": torch.float16, "f16": torch.float16
 _IO_THREADS = max(8, min(32, (os.cpu_count() or 8) // 2))
 
 
+class _StageClock:
+    """Wall-clock totals per pipeline stage, printed at the end of a command when ``$DSS_CLI_TIMING`` is set."""
+
+    def __init__(self):
+        import time
+        self.t, self.acc, self.on = time.perf_counter, {}, bool(os.environ.get("DSS_CLI_TIMING"))
+
+    def __call__(self, name: str):
+        clock = self
+
+        class _ctx:
+            def __enter__(self):
+                self.t0 = clock.t()
+
+            def __exit__(self, *exc):
+                clock.acc[name] = clock.acc.get(name, 0.0) + clock.t() - self.t0
+                return False
+
+        return _ctx()
+
+    def report(self, what: str):
+        if self.on:
+            print(f"[dss] {what} stage totals (s): " + ", ".join(f"{k} {v:.2f}" for k, v in self.acc.items()))
+
+
+def _cap_host_threads():
+    """The commands' host-side torch work is copies and slicing: on a 256-core box the default intra-op pool (one thread
+    per core, spinning after every parallel region) only takes cycles from the decoder / loader / saver processes."""
+    if torch.get_num_threads() > 8:
+        torch.set_num_threads(8)
+
+
+def _start_method() -> str:
+    """How the I/O worker processes are started: ``spawn`` (they re-import torch, 1.5-2 s, while the parent keeps
+    working - the job queue is deep enough to absorb that).  ``$DSS_IO_START_METHOD=fork`` was measured on the GPU box:
+    workers are up in milliseconds, but the parent - which holds the HIP context - then runs its own copies 4-5x slower
+    (extract_eigs 352 vs 633 images/s on 2 048 files), so it is not the default."""
+    return os.environ.get("DSS_IO_START_METHOD", "spawn")
+
+
 class _spawn_without_main:
     """``spawn`` children normally re-import the parent's ``__main__`` - a caller's script without an
     ``if __name__ == "__main__"`` guard would then run again inside every I/O worker.  The workers here only need this
@@ -95,6 +135,8 @@ class _AsyncSaver:
     (``processes > 0``): worker PROCESSES fed whole batches through shared memory (``submit_batch``), so the per-image
     pickling runs in parallel; ``close()`` waits for everything and re-raises the first error."""
 
+    RING = 6   # shared blocks a producer may cycle through (extract_features: features of one batch each)
+
     def __init__(self, threads: int = _IO_THREADS, max_pending: int = 1024, processes: int = 0):
         self.pool = ThreadPoolExecutor(max_workers=threads)
         self.futures: List = []
@@ -104,9 +146,14 @@ class _AsyncSaver:
         if processes > 0:
             import torch.multiprocessing as mp
 
-            ctx = mp.get_context("spawn")      # never fork a process that holds a HIP context
-            self.queue, self.errors = ctx.Queue(maxsize=2 * processes), ctx.Queue()
-            self.procs = [ctx.Process(target=_pkg._save_worker, args=(self.queue, self.errors), daemon=True)
+            ctx = mp.get_context(_start_method())
+            # deep enough that the producer is not held up while the workers are still importing torch
+            self.queue, self.errors = ctx.Queue(maxsize=64 * processes), ctx.Queue()
+            # chunks finished per ring slot (``submit_batch(..., slot=)``): the producer reuses a shared block only
+            # after every chunk cut from its previous contents has been written
+            self.done = [ctx.Value("l", 0) for _ in range(self.RING)]
+            self.sent = [0] * self.RING
+            self.procs = [ctx.Process(target=_pkg._save_worker, args=(self.queue, self.errors, self.done), daemon=True)
                           for _ in range(processes)]
             with _spawn_without_main():
                 for p in self.procs:
@@ -120,16 +167,28 @@ class _AsyncSaver:
                 f.result()
             self.waited = upto
 
-    def submit_batch(self, kind: str, tensors: Tuple[torch.Tensor, ...], items: List[tuple], chunk: int = 16):
+    def submit_batch(self, kind: str, tensors: Tuple[torch.Tensor, ...], items: List[tuple], chunk: int = 16,
+                     slot: Optional[int] = None):
         """``items`` (one tuple per file, see ``_SAVE_BUILDERS[kind]``) index into the batch ``tensors`` (host tensors;
-        moved to shared memory once per batch).  Without worker processes the files are built here and saved by threads."""
+        moved to shared memory once per batch).  Without worker processes the files are built here and saved by threads.
+        ``slot``: the tensors live in ring block ``slot`` (``wait_slot`` before overwriting it)."""
         if not self.procs:
             for it in items:
                 self.submit(*_SAVE_BUILDERS[kind](tensors, it), writer=_SAVE_WRITERS.get(kind, torch.save))
             return
         tensors = tuple(t if t.is_shared() else t.share_memory_() for t in tensors)
         for s in range(0, len(items), chunk):
-            self._put((kind, tensors, items[s:s + chunk]))
+            if slot is not None:
+                self.sent[slot] += 1
+            self._put((kind, tensors, items[s:s + chunk], slot))
+
+    def wait_slot(self, slot: int):
+        """Blocks until the workers have written every file cut from ring block ``slot``."""
+        import time
+        while self.procs and self.done[slot].value < self.sent[slot]:
+            if not all(p.is_alive() for p in self.procs):
+                raise RuntimeError("a saver process died")
+            time.sleep(0.001)
 
     def _put(self, job):
         import queue
@@ -189,61 +248,190 @@ _SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file, "png
 _SAVE_WRITERS = {"png": _write_png}     # everything else: torch.save
 
 
-def _save_worker(queue, errors):
+def _save_worker(queue, errors, done=None):
     torch.set_num_threads(1)
     while True:
         job = queue.get()
         if job is None:
             return
-        kind, tensors, items = job
+        kind, tensors, items, slot = job
         try:
             for it in items:
                 _SAVE_WRITERS.get(kind, torch.save)(*_SAVE_BUILDERS[kind](tensors, it))
         except BaseException as e:  # reported by close() in the parent
             errors.put(f"{type(e).__name__}: {e}")
         del tensors, job
+        if slot is not None:   # also after a failure: the producer must not wait for ever
+            with done[slot].get_lock():
+                done[slot].value += 1
 
 
-def _load_feature_chunk(args):
-    """Worker side of the ``extract_eigs`` loader: read a chunk of feature files, return ``[(meta dicts, features
-    [n, N, D] f32)]`` with one entry per distinct feature shape - the big tensors travel back through shared memory."""
-    files, which_features = args
-    torch.set_num_threads(1)
-    groups: Dict[Tuple[int, ...], Tuple[list, list]] = {}
-    for f in files:
-        data_dict, feats = _load_features(str(f), which_features)
-        # small tensors (the 0-d `indices`) travel as Python values: a tensor would cross the process boundary as its own
-        # shared-memory storage - one file descriptor per file, hundreds in flight with 32-file chunks
-        meta = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in data_dict.items()
-                if not torch.is_tensor(v) or v.numel() <= 16}
-        metas, tensors = groups.setdefault(tuple(feats.shape), ([], []))
-        metas.append(meta), tensors.append(feats)
-    return [(metas, torch.stack(tensors)) for metas, tensors in groups.values()]
+class _ShmBlocks:
+    """Up to ``count`` blocks of ``size`` bytes in /dev/shm that worker processes fill (``pthfast`` maps them by path)
+    and the GPU reads: every block is wrapped as a u8 tensor and page-locked (best effort; measured on the GPU box: a
+    0.69 MB H2D takes 0.024 ms out of a registered block, 0.145 ms out of an unregistered one).  Blocks are created one
+    at a time (``add``) so that the first workers are busy while the later blocks are still being set up."""
+
+    def __init__(self, count: int, size: int):
+        self.count, self.size, self.paths, self.maps, self.tensors = count, size, [], [], []
+
+    def add(self) -> int:
+        import mmap
+
+        i = len(self.paths)
+        path = f"/dev/shm/dss_{os.getpid()}_{id(self) & 0xffff:x}_{i}"
+        fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+        try:
+            os.posix_fallocate(fd, 0, self.size)   # the pages exist (zeroed by the kernel, no fault per page) before
+            m = mmap.mmap(fd, self.size)           # they are page-locked
+        finally:
+            os.close(fd)
+        t = torch.frombuffer(m, dtype=torch.uint8)
+        try:
+            torch.cuda.cudart().cudaHostRegister(t.data_ptr(), self.size, 0)
+        except Exception:  # pragma: no cover - pageable copies still work
+            pass
+        self.paths.append(path), self.maps.append(m), self.tensors.append(t)
+        return i
+
+    def close(self):
+        for t in self.tensors:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+            except Exception:  # pragma: no cover
+                pass
+        self.tensors.clear()
+        for path in self.paths:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        self.paths.clear()
 
 
-def _iter_features(files, which_features: str, processes: int, window: int):
-    """Yields ``(data_dict without the features, features [N, D] f32)`` for every file of ``files``: loaded by a thread
-    pool (small runs) or by worker processes in chunks of 32 files with at most ``2 * processes`` chunks in flight."""
-    if processes <= 0:
-        with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
-            yield from _bounded_map(pool, lambda f: _load_features(str(f), which_features), files, window)
-        return
+def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, block_bytes: int):
+    """Runs ``fn(block path, block size, chunk, *extra_args)`` of ``pthfast`` for every chunk on ``processes`` torch-free
+    worker processes, each call filling one page-locked /dev/shm block.  Yields ``(entries, block tensor u8, release)``
+    in chunk order; the consumer enqueues its copies out of the block on the current stream and then calls
+    ``release()`` - the block goes back to the workers once those copies have finished."""
     import torch.multiprocessing as mp
     from collections import deque
 
-    chunks = [(files[s:s + 32], which_features) for s in range(0, len(files), 32)]
+    import time
+    t_start = time.perf_counter()
     with _spawn_without_main():
-        pool = mp.get_context("spawn").Pool(processes)
-    with pool:
-        pending = deque()
-        for c in chunks:
-            pending.append(pool.apply_async(_pkg._load_feature_chunk, (c,)))
-            while len(pending) >= 2 * processes:
-                for metas, stacked in pending.popleft().get(timeout=600):   # a lost worker must not hang the run
-                    yield from zip(metas, stacked)
-        while pending:
-            for metas, stacked in pending.popleft().get(timeout=600):
-                yield from zip(metas, stacked)
+        pool = mp.get_context(_start_method()).Pool(processes)   # first: the workers boot while the blocks are pinned
+    blocks = _ShmBlocks(processes + 2, block_bytes)
+    first = None
+    try:
+        with pool:
+            free, events = deque(), [None] * blocks.count
+            pending, nxt = deque(), 0
+
+            def releaser(b):
+                def release():
+                    events[b] = torch.cuda.Event()
+                    events[b].record()
+                    free.append(b)
+                return release
+
+            while nxt < len(chunks) or pending:
+                while (free or len(blocks.paths) < blocks.count) and nxt < len(chunks):
+                    b = free.popleft() if free else blocks.add()
+                    if events[b] is not None:
+                        events[b].synchronize()     # the copies out of this block have finished
+                    pending.append((pool.apply_async(fn, (blocks.paths[b], blocks.size, chunks[nxt]) + extra_args), b))
+                    nxt += 1
+                res, b = pending.popleft()
+                got = res.get(timeout=600)          # a lost worker must not hang the run
+                if first is None:
+                    first = time.perf_counter() - t_start
+                yield got, blocks.tensors[b], releaser(b)
+    finally:
+        blocks.close()
+        if os.environ.get("DSS_CLI_TIMING") and first is not None:
+            print(f"[dss] {fn.__name__}: {processes} workers, first chunk after {first:.2f} s, all {len(chunks)} chunks "
+                  f"after {time.perf_counter() - t_start:.2f} s")
+
+
+def _iter_features(files, which_features: str, processes: int, window: int, device: Optional[torch.device] = None):
+    """Yields ``(data_dict without the features, features [N, D] f32)`` for every file of ``files``, in order.  Small
+    runs: ``torch.load`` on a thread pool, host tensors.  Large runs on a GPU: ``processes`` torch-free loader processes
+    (``pthfast.load_chunk``) read chunks of 16 files straight into page-locked /dev/shm blocks; the rows are copied to
+    ``device`` from there (one async H2D per run of same-shape files) and yielded as DEVICE tensors."""
+    if processes <= 0 or device is None or device.type != "cuda":
+        with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
+            yield from _bounded_map(pool, lambda f: _load_features(str(f), which_features), files, window)
+        return
+    from . import pthfast
+
+    per = 16
+    chunks = [[str(f) for f in files[s:s + per]] for s in range(0, len(files), per)]
+    biggest = max(os.path.getsize(f) for f in files)    # a file's size bounds its f32 feature bytes
+    for entries, block, release in _pump_chunks(pthfast.load_chunk, chunks, (which_features,), processes, per * biggest):
+        i = 0
+        while i < len(entries):
+            meta, off, shape = entries[i]
+            if meta is None:                # (None, file, reason): not a plain feature archive
+                yield _load_features(off, which_features)
+                i += 1
+                continue
+            j, nbytes = i + 1, 4 * shape[0] * shape[1]
+            while j < len(entries) and entries[j][0] is not None and entries[j][2] == shape \
+                    and entries[j][1] == off + (j - i) * nbytes:
+                j += 1
+            rows = block[off:off + (j - i) * nbytes].view(torch.float32).view((j - i,) + tuple(shape))
+            dev = rows.to(device, non_blocking=True)
+            for n in range(j - i):
+                yield entries[i + n][0], dev[n]
+            i = j
+        release()
+
+
+def _iter_images(dataset, todo, processes: int, window: int, device: torch.device):
+    """Yields ``(u8 RGB [H, W, 3] image, file name)`` for every ``(index, output)`` of ``todo``, in order.  Small runs:
+    PIL on a thread pool, page-locked host tensors.  Large runs: ``processes`` torch-free decoder processes
+    (``pthfast.decode_chunk``) fill page-locked /dev/shm blocks and the images are yielded as DEVICE tensors."""
+    if processes <= 0 or device.type != "cuda":
+        def decode(t):
+            img, file, _ = dataset[t[0]]
+            return img.pin_memory() if device.type == "cuda" else img, file   # the copy into page-locked memory: here
+
+        with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:  # decode pool (the reference: 8 loader processes)
+            yield from _bounded_map(pool, decode, todo, window)
+        return
+    from . import pthfast
+
+    per = 16
+    names = [dataset.filenames[i] for i, _ in todo]
+    paths = [str(n if dataset.root is None else dataset.root / n) for n in names]
+    chunks = [paths[s:s + per] for s in range(0, len(paths), per)]
+    at = 0
+    # 1.5 MB per image on average (VOC: <= 500 x 500 x 3 = 0.75 MB); what does not fit a block is decoded here
+    for entries, block, release in _pump_chunks(pthfast.decode_chunk, chunks, (), processes, per * (3 << 19)):
+        for off, shape in entries:
+            if off is None:                # did not fit the block: decode it here
+                img = dataset[todo[at][0]][0].to(device)
+            else:
+                n = shape[0] * shape[1] * shape[2]
+                img = block[off:off + n].view(shape).to(device, non_blocking=True)
+            yield img, names[at]
+            at += 1
+        release()
+
+
+def _shared_pinned_block(numel: int, dtype: torch.dtype) -> torch.Tensor:
+    """A shared-memory tensor (worker processes map it) that is also page-locked for the GPU's copy engine.  Registration
+    is best effort: without it the copies still work, through the driver's bounce buffers."""
+    t = torch.empty(numel, dtype=dtype).share_memory_()
+    t.zero_()    # touch every page once, here
+    try:
+        rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+        if int(rc) != 0:
+            print(f"[dss] note: hipHostRegister of a {t.numel() * t.element_size() >> 20} MiB block returned {int(rc)}")
+    except Exception as e:  # pragma: no cover - depends on the runtime
+        print(f"[dss] note: could not page-lock a shared block ({e})")
+    return t
 
 
 def _shm_free_bytes() -> int:
@@ -255,12 +443,12 @@ def _shm_free_bytes() -> int:
 
 
 def _io_processes(n_items: int, most: int = 16) -> int:
-    """Worker processes for the per-image file I/O of a run of ``n_items`` files on this rank: none for small runs (a
-    spawned interpreter costs ~2 s), otherwise a share of the host cores, at most ``most`` (``$DSS_IO_PROCESSES``
-    overrides)."""
+    """Worker processes for the per-image file I/O of a run of ``n_items`` files on this rank: none for small runs,
+    otherwise a share of the host cores, at most ``most`` (``$DSS_IO_PROCESSES`` overrides)."""
     if os.environ.get("DSS_IO_PROCESSES"):
         return int(os.environ["DSS_IO_PROCESSES"])
-    if n_items < 512 or _shm_free_bytes() < (8 << 30):   # batches travel through /dev/shm: needs room
+    few = 512 if _start_method() == "spawn" else 64   # a spawned interpreter costs ~2 s, a forked one milliseconds
+    if n_items < few or _shm_free_bytes() < (8 << 30):   # batches travel through /dev/shm: needs room
         return 0
     local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
     return max(2, min(most, (os.cpu_count() or 8) // (4 * max(1, local))))
@@ -307,13 +495,12 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
     whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76)."""
     _make_output_dir_all_ranks(output_dir)
+    _cap_host_threads()
     model_name = model_name.lower()
     if not ("dino" in model_name or "mocov3" in model_name):
         raise ValueError(model_name)
     rank, world = rank_world()
     device = local_device()
-    model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
-                                              weights=weights, synthetic_seed=synthetic_weights)
 
     filenames = Path(images_list).read_text().splitlines()
     dataset = utils.ImagesDataset(filenames=filenames, images_root=images_root, transform=None)
@@ -326,41 +513,108 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
             continue
         todo.append((i, out))
 
-    saver = _AsyncSaver(processes=_io_processes(len(todo)))
+    bs = max(1, int(batch_size))
+    clock = _StageClock()
+    with clock("start savers"):   # first of all: the saver processes import torch while the model is being built
+        saver = _AsyncSaver(processes=_io_processes(len(todo)))
+    decoders = _io_processes(len(todo), most=12) if saver.procs else 0   # ~1.1 ms of PIL per 480 x 480 JPEG
+    with clock("model"):
+        model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
+                                                  weights=weights, synthetic_seed=synthetic_weights)
+
+    # One batch travels: page-locked decoded images -> async H2D + ViT -> a drain thread that waits for the batch, copies
+    # the features into a page-locked shared-memory block the saver processes map and hands the files over.  The main
+    # thread is back at the decoded-image queue while the GPU and the drain thread work on the previous batches.
+    import queue as _queue
+    import threading
+    ring = {"blocks": [None] * _AsyncSaver.RING, "next": 0}
+    copy_stream = torch.cuda.Stream(device=device)
+    drain_q: "_queue.Queue" = _queue.Queue(maxsize=3)
+    drain_err: List[BaseException] = []
+
+    def drain():
+        while True:
+            job = drain_q.get()
+            if job is None:
+                return
+            try:
+                k_dev, done, metas = job
+                slot = None
+                with clock("drain: shared block"):
+                    if saver.procs:
+                        # a ring of shared-memory blocks the saver processes map, page-locked once: a fresh segment
+                        # per batch cost 90 ms of page faults plus a 1.5 GB/s pageable D2H (177 MB per 128 images)
+                        slot = ring["next"] % saver.RING
+                        ring["next"] += 1
+                        saver.wait_slot(slot)
+                        need = k_dev.numel()
+                        if ring["blocks"][slot] is None or ring["blocks"][slot].numel() < need:
+                            ring["blocks"][slot] = _shared_pinned_block(need, k_dev.dtype)
+                        k = ring["blocks"][slot][:need].view(k_dev.shape)
+                    else:
+                        k = torch.empty(k_dev.shape, dtype=k_dev.dtype)
+                with clock("drain: wait + D2H"), torch.cuda.stream(copy_stream):   # not behind the next batch's ViT
+                    copy_stream.wait_event(done)
+                    k_dev.record_stream(copy_stream)
+                    k.copy_(k_dev, non_blocking=True)
+                    copy_stream.synchronize()
+                del k_dev
+                with clock("drain: hand to savers"):
+                    saver.submit_batch("features", (k,), metas, slot=slot)
+            except BaseException as e:  # re-raised by the main thread
+                drain_err.append(e)
+
+    drainer = threading.Thread(target=drain, daemon=True)
+    drainer.start()
 
     def flush(batch: List[Tuple[int, Path, torch.Tensor, str]]):
         if not batch:
             return
-        imgs = torch.stack([b[2] for b in batch]).to(device, non_blocking=True)
-        k_dev = model.extract_k(imgs, which_block=which_block)
-        k = torch.empty(k_dev.shape, dtype=k_dev.dtype)
-        if saver.procs:
-            k.share_memory_()          # D2H straight into the segment the saver processes map
-        k.copy_(k_dev)
-        shape = (1, 3, int(imgs.shape[1]), int(imgs.shape[2]))
-        saver.submit_batch("features", (k,), [(j, idx, file, model_name, patch_size, shape, str(out))
-                                              for j, (idx, out, _, file) in enumerate(batch)])
+        if drain_err:
+            raise drain_err[0]
+        with clock("flush: enqueue H2D + ViT"):
+            # no host-side stacking pass: torch.stack of 128 decoded images into fresh pageable memory cost 265 ms
+            # the images arrive page-locked (decode threads) or already on the device (decoder processes): one call
+            # gathers the batch - every Python-level call gives the GIL away and queues to get it back
+            imgs = torch.empty((len(batch),) + tuple(batch[0][2].shape), dtype=torch.uint8, device=device)
+            torch._foreach_copy_(list(imgs.unbind(0)), [b[2] for b in batch], non_blocking=True)
+            k_dev = model.extract_k(imgs, which_block=which_block)
+            done = torch.cuda.Event()
+            done.record()
+        shp = (1, 3, int(imgs.shape[1]), int(imgs.shape[2]))
+        with clock("flush: drain queue full"):
+            drain_q.put((k_dev, done, [(j, idx, file, model_name, patch_size, shp, str(out))
+                                       for j, (idx, out, _, file) in enumerate(batch)]))
         batch.clear()
 
     # Real datasets (VOC) mix image sizes: bucket by shape so every ViT launch is a full same-shape batch.  At most
     # `max_pending` decoded images wait in the buckets; beyond that the fullest bucket is flushed early.
     buckets: Dict[Tuple[int, ...], List[Tuple[int, Path, torch.Tensor, str]]] = {}
-    bs, max_pending, n_pending = max(1, int(batch_size)), 8 * max(1, int(batch_size)), 0
-    with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:  # decode pool (the reference: 8 loader processes)
-        for (idx, out), (img, file, _) in zip(todo, _bounded_map(pool, lambda t: dataset[t[0]], todo, 4 * bs)):
-            bucket = buckets.setdefault(tuple(img.shape), [])
-            bucket.append((idx, out, img, file))
-            n_pending += 1
-            if len(bucket) >= bs:
-                n_pending -= len(bucket)
-                flush(bucket)
-            elif n_pending >= max_pending:
-                fullest = max(buckets.values(), key=len)
-                n_pending -= len(fullest)
-                flush(fullest)
-        for bucket in buckets.values():
+    max_pending, n_pending = 8 * bs, 0
+    decoded = _iter_images(dataset, todo, decoders, 4 * bs, device)
+    for idx, out in todo:
+        with clock("wait for decoded image"):
+            img, file = next(decoded)
+        bucket = buckets.setdefault(tuple(img.shape), [])
+        bucket.append((idx, out, img, file))
+        n_pending += 1
+        if len(bucket) >= bs:
+            n_pending -= len(bucket)
             flush(bucket)
-    saver.close()
+        elif n_pending >= max_pending:
+            fullest = max(buckets.values(), key=len)
+            n_pending -= len(fullest)
+            flush(fullest)
+    for bucket in buckets.values():
+        flush(bucket)
+    with clock("tail: drain thread"):
+        drain_q.put(None)
+        drainer.join()
+    if drain_err:
+        raise drain_err[0]
+    with clock("tail: savers finish"):
+        saver.close()
+    clock.report("extract_features")
     _barrier()
     print(f"Saved features to {output_dir}")
 
@@ -532,6 +786,7 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     still on the device (``spectral.single_region_masks`` / ``multi_region_segments``; the Laplacian branches only),
     with those commands' own options (``segmentation_threshold`` is their ``threshold``)."""
     _make_output_dir_all_ranks(output_dir)
+    _cap_host_threads()
     for extra in (single_region_dir, multi_region_dir):
         if extra:
             if which_matrix not in ("laplacian", "matting_laplacian"):
@@ -576,8 +831,16 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
     # torch.load of a 1.4 MB feature file costs ~0.6 ms and torch.save of an 18 KB eigen file less: few workers do
     nproc = _io_processes(len(mine), most=8)
-    saver = _AsyncSaver(processes=min(nproc, 4))
-    for data_dict, feats in _iter_features(mine, which_features, nproc, 4 * bs):
+    clock = _StageClock()
+    with clock("start savers"):
+        saver = _AsyncSaver(processes=min(nproc, 4))
+    loaded = _iter_features(mine, which_features, nproc, 4 * bs, device)
+    while True:
+        with clock("wait for loaded features"):
+            nxt = next(loaded, None)
+        if nxt is None:
+            break
+        data_dict, feats = nxt
         image_id = data_dict["file"][:-4]
         output_file = str(Path(output_dir) / f"{image_id}.pth")
         if Path(output_file).is_file():
@@ -597,10 +860,14 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
         if len(pending[key]) >= bs or n_pending >= max_pending:
             n_pending -= len(pending[key])
-            run(key)
+            with clock("run batches"):
+                run(key)
     for key in list(pending):
-        run(key)
-    saver.close()
+        with clock("run batches"):
+            run(key)
+    with clock("tail: savers finish"):
+        saver.close()
+    clock.report("extract_eigs")
     _barrier()
 
 

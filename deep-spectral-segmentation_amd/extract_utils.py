@@ -52,17 +52,12 @@ class ImagesDataset:
         return len(self.filenames)
 
     def __getitem__(self, index: int) -> Tuple[Any, str, int]:
-        from PIL import Image
+        from .pthfast import decode_rgb
 
         path = self.filenames[index]
         full_path = Path(path) if self.root is None else self.root / path
         assert full_path.is_file(), f"Not a file: {full_path}"
-        from PIL import ImageOps
-
-        with Image.open(full_path) as im:
-            # cv2.imread (the reference's decoder, extract_utils.py:30) applies the EXIF orientation; PIL does not
-            # unless asked to
-            image = torch.from_numpy(np.array(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8))
+        image = torch.from_numpy(decode_rgb(full_path))
         if self.transform is not None:
             image = self.transform(image)
         return image, path, index

@@ -472,3 +472,50 @@ def test_bbox_clusters_and_semantic_segmentations_match_reference(tmp_path, run)
     torch.save([{"id": "bin", "bboxes": [[0, 0, 1, 1]], "segment_indices": [1], "clusters": np.array([7])}], tmp_path / "cb.pth")
     extract.extract_semantic_segmentations(str(tmp_path / "s"), str(tmp_path / "cb.pth"), str(tmp_path / "semb"))
     assert set(np.unique(np.array(Image.open(tmp_path / "semb" / "bin.png"))).tolist()) <= {0, 7}
+
+
+def test_pthfast_reads_feature_files_without_torch_semantics_lost(tmp_path):
+    """The torch-free reader of the extract_eigs loader processes against torch.load on the reference's feature schema
+    (extract/extract.py:98-110), including half features, a strided tensor (reported, not mis-read) and a foreign
+    pickled class (reported)."""
+    import mmap
+    import os
+
+    import numpy as np
+    import torch
+
+    from dss_amd import pthfast
+
+    files = []
+    for i, (n, d, dt) in enumerate([(48, 384, torch.float32), (35, 64, torch.float32), (48, 384, torch.float16)]):
+        k = torch.randn(1, n, d).to(dt)
+        f = tmp_path / f"f{i}.pth"
+        torch.save({"k": k, "indices": torch.tensor(7 + i), "file": f"im{i}.jpg", "id": f"im{i}", "model_name": "dino_vits16",
+                    "patch_size": 16, "shape": (1, 3, 96, 128)}, f)
+        files.append((str(f), k))
+    strided = tmp_path / "strided.pth"
+    torch.save({"k": torch.randn(1, 64, 48).transpose(1, 2), "file": "s.jpg", "patch_size": 16, "shape": (1, 3, 96, 128)}, strided)
+    foreign = tmp_path / "foreign.pth"
+    torch.save({"k": torch.randn(1, 4, 4), "extra": np.arange(3), "file": "g.jpg", "patch_size": 16, "shape": (1, 3, 32, 32)}, foreign)
+    block, size = tmp_path / "block", 1 << 20
+    with open(block, "wb") as fh:
+        fh.truncate(size)
+    out = pthfast.load_chunk(str(block), size, [f for f, _ in files] + [str(strided), str(foreign)], "k")
+    assert len(out) == 5
+    with open(block, "r+b") as fh:
+        m = mmap.mmap(fh.fileno(), size)
+    expect_off = 0
+    for (f, k), (meta, off, shape) in zip(files, out[:3]):
+        assert off == expect_off and shape == tuple(k.shape[1:])
+        got = np.frombuffer(m, dtype=np.float32, count=k.numel(), offset=off).reshape(shape)
+        assert np.array_equal(got, k[0].float().numpy())
+        ref = torch.load(f, weights_only=True)
+        assert meta == {"indices": int(ref["indices"]), "file": ref["file"], "id": ref["id"], "model_name": ref["model_name"],
+                        "patch_size": 16, "shape": (1, 3, 96, 128)}
+        expect_off += 4 * k.numel()
+    assert out[3][0] is None and out[3][1] == str(strided) and "strided" in out[3][2]
+    assert out[4][0] is None and out[4][1] == str(foreign) and "numpy" in out[4][2]
+    # a block too small for the chunk: the overflow is reported per file, nothing is written past the end
+    small = pthfast.load_chunk(str(block), 4 * 48 * 384 + 16, [files[0][0], files[1][0]], "k")
+    assert small[0][0] is not None and small[1][0] is None and "block full" in small[1][2]
+    assert "torch" not in pthfast.__dict__

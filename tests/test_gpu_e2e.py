@@ -3,6 +3,8 @@ the .pth schemas, and eigenvector parity of the whole path (BASELINE.json: 1 - |
 from pathlib import Path
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -403,6 +405,45 @@ def test_cli_two_stage_roundtrip_and_resume(tmp_path, capsys):
     # <images_root>/<id>.jpg - the synthetic images here are PNGs, as in the reference the open() fails
     with pytest.raises(FileNotFoundError):
         extract._extract_eig((0, str(tmp_path / "feat" / "a_000.pth")), K=3, images_root="", output_dir=str(tmp_path / "eigs2"))
+
+
+def test_cli_worker_process_io_matches_the_in_process_path(tmp_path, monkeypatch):
+    """Large runs move the file I/O into worker processes (saver ring of page-locked shared blocks in
+    extract_features; torch-free `pthfast` loaders filling /dev/shm blocks in extract_eigs).  Forced on here for a small
+    mixed-size set: every output file must equal the in-process path's, tensor for tensor."""
+    specs = [(f"p_{i:03d}.png", 50 + i, 96, 128) if i % 3 else (f"p_{i:03d}.png", 50 + i, 128, 96) for i in range(41)]
+    _write_images(tmp_path / "images", specs)
+    (tmp_path / "images.txt").write_text("\n".join(s[0] for s in specs) + "\n")
+    common = ["--images_root", str(tmp_path / "images")]
+
+    def run(tag):
+        extract.main(["extract_features", "--images_list", str(tmp_path / "images.txt"), *common, "--output_dir",
+                      str(tmp_path / f"feat{tag}"), "--model_name", "dino_vits16", "--batch_size", "8",
+                      "--synthetic_weights", "3"])
+        extract.main(["extract_eigs", *common, "--features_dir", str(tmp_path / f"feat{tag}"), "--output_dir",
+                      str(tmp_path / f"eigs{tag}"), "--K", "4", "--batch_size", "16"])
+
+    monkeypatch.setenv("DSS_IO_PROCESSES", "0")
+    run("_threads")
+    monkeypatch.setenv("DSS_IO_PROCESSES", "3")
+    run("_procs")
+    assert not list(Path("/dev/shm").glob(f"dss_{os.getpid()}_*")), "shared blocks left behind"
+    for sub in ("feat", "eigs"):
+        a_dir, b_dir = tmp_path / f"{sub}_threads", tmp_path / f"{sub}_procs"
+        assert sorted(p.name for p in a_dir.iterdir()) == sorted(p.name for p in b_dir.iterdir()) and len(list(a_dir.iterdir())) == 41
+        for fa in sorted(a_dir.iterdir()):
+            a = torch.load(fa, map_location="cpu", weights_only=True)
+            b = torch.load(b_dir / fa.name, map_location="cpu", weights_only=True)
+            assert sorted(a) == sorted(b)
+            for key in a:
+                if torch.is_tensor(a[key]):
+                    assert a[key].dtype == b[key].dtype and a[key].shape == b[key].shape
+                    if sub == "feat":
+                        assert torch.equal(a[key], b[key]), (fa.name, key)
+                    else:   # the solver's LDS atomics: reproducible to rounding, not bitwise
+                        assert torch.allclose(a[key], b[key], atol=2e-5), (fa.name, key)
+                else:
+                    assert a[key] == b[key], (fa.name, key)
 
 
 def test_cli_two_ranks_shard_round_robin(tmp_path):
