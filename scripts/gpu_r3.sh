@@ -52,6 +52,25 @@ d = json.loads(open('gpurun_out/bench_ds$DS.json').read())
 print('dataset $DS:', {k: d[k] for k in ('value', 'ms_per_step', 'steps', 'scaling')}, d['config']['workload'])
 "; done;;
     bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
+    bench_c3) timeout 900 python bench.py --model dino_vitb8 --K 15 --batch 512 --vit-batch 16 --cpu-images 2 --parity-images 2 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; echo "bench_c3 exit: $?"; tail -2 gpurun_out/bench_c3.err; cut -c1-600 gpurun_out/bench_c3.json;;
+    bench_c1) timeout 600 python bench.py --size 224 --cpu-images 8 --parity-images 8 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c1.json 2> gpurun_out/bench_c1.err; echo "bench_c1 exit: $?"; tail -2 gpurun_out/bench_c1.err; cut -c1-400 gpurun_out/bench_c1.json;;
+    prof)   # per-kernel time of the bench command (rocprofv3 kernel trace + stats); PROF_TAG names the output
+      T=${PROF_TAG:-c2}; rm -rf gpurun_out/prof_$T && mkdir -p gpurun_out/prof_$T
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO_DIR/gpurun_out/prof_$T -o bench -- python $REPO_DIR/bench.py --steps 2 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 --dino-like-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/prof_$T/bench.json 2> $REPO_DIR/gpurun_out/prof_$T/bench.err)
+      echo "prof exit: $?"; python scripts/rocpd_summary.py gpurun_out/prof_$T/bench_results.db > gpurun_out/kernel_stats_$T.csv; head -14 gpurun_out/kernel_stats_$T.csv | cut -c1-200
+      rm -rf gpurun_out/prof_$T;;
+    pmc)    # hardware counters, ONE rocprofv3 pass per group (--kernel-trace only); PMC_GROUPS restricts, PROF_TAG names
+      T=${PROF_TAG:-c2}
+      declare -A PMCG=( [mfma]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+                          [wait]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES"
+                          [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" )
+      for G in ${PMC_GROUPS:-mfma wait fetch write}; do
+        rm -rf gpurun_out/pmcrun_$G && mkdir -p gpurun_out/pmcrun_$G
+        (cd /tmp && timeout 600 rocprofv3 --pmc ${PMCG[$G]} --kernel-trace -d $REPO_DIR/gpurun_out/pmcrun_$G -o pmc -- python $REPO_DIR/bench.py --steps 1 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 --dino-like-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/pmc_${T}_$G.bench.json 2> $REPO_DIR/gpurun_out/pmcrun_$G/bench.err)
+        echo "pmc $G exit: $?"
+        python scripts/rocpd_pmc_multi.py gpurun_out/pmcrun_$G/pmc_results.db 2 > gpurun_out/pmc_${T}_$G.csv; head -6 gpurun_out/pmc_${T}_$G.csv | cut -c1-220
+        rm -rf gpurun_out/pmcrun_$G
+      done;;
     *) echo "unknown stage $STAGE";;
   esac
 done

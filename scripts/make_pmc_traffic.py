@@ -18,6 +18,7 @@ KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_",
     "layernorm": "layernorm_kernel",
+    "kfeatures_finalize": "kfeatures_finalize_kernel",
     "normalize_rows_split": "normalize_rows_split_kernel",
     "torch_gelu (FETCH_SIZE calibration)": "GeluCUDAKernelImpl",
 }
