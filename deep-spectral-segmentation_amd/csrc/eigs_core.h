@@ -48,7 +48,7 @@
 #define DSS_TID ((int)threadIdx.x)
 #define DSS_NT ((int)blockDim.x)
 #define DSS_LANE ((int)(threadIdx.x & 63))
-#define DSS_WAVE ((int)(threadIdx.x >> 6))
+#define DSS_WAVE (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))   /* wave-uniform: tile indices and their addresses stay scalar */
 #define DSS_NWAVES ((int)(blockDim.x >> 6))
 #define DSS_LANES 64
 #define DSS_SYNC() __syncthreads()
@@ -240,6 +240,76 @@ template <class WE> struct WElem;
 template <> struct WElem<float> { static constexpr float scale = 1.0f; };
 template <> struct WElem<uint16_t> { static constexpr float scale = 65535.0f; };
 
+#ifndef DSS_HOST_EMUL
+// value of lane ^ M without an address register: ds_swizzle (bit-mask mode, xor inside 32 lanes) / v_permlane32_swap.
+// (__shfl_xor builds a byte address per mask from the lane id; six of them live through the tile loop were six of the
+// registers hipcc spilled there.)
+template <int M>
+DSS_DEV float lane_xor(float v, int lane) {
+  if constexpr (M < 32) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
+  } else {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0]: upper half <- lower, r[1]: lower <- upper
+    const unsigned lo = r[0], hi = r[1];
+    return __builtin_bit_cast(float, lane < 32 ? hi : lo);
+  }
+}
+
+// The reductions of one tile: rp[k] = partial of tile row 4k + g over this lane's 4 columns, c0..c3 = partials of
+// columns 4q..4q+3 over this lane's 16 rows.  Halving butterflies leave every lane one finished row sum and one
+// finished column sum, added to the LDS accumulator.
+DSS_DEV void matvec_finish_tile(float (&rp)[16], float c0_, float c1_, float c2_, float c3_, int I, int J, int lane,
+                                float* ws) {
+  const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool up = (q & 8) != 0;
+    const float send = up ? rp[k] : rp[k + 8];
+    const float keep = up ? rp[k + 8] : rp[k];
+    rp[k] = keep + lane_xor<8>(send, lane);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool up = (q & 4) != 0;
+    const float send = up ? rp[k] : rp[k + 4];
+    const float keep = up ? rp[k + 4] : rp[k];
+    rp[k] = keep + lane_xor<4>(send, lane);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool up = (q & 2) != 0;
+    const float send = up ? rp[k] : rp[k + 2];
+    const float keep = up ? rp[k + 2] : rp[k];
+    rp[k] = keep + lane_xor<2>(send, lane);
+  }
+  {
+    const bool up = (q & 1) != 0;
+    const float send = up ? rp[0] : rp[1];
+    const float keep = up ? rp[1] : rp[0];
+    rp[0] = keep + lane_xor<1>(send, lane);
+  }
+  atomicAdd(&ws[I * WT + 4 * q + g], rp[0]);   // row k = q, i.e. tile row 4 q + g
+  if (I != J) {
+    float c0, c1;
+    {
+      const bool up = (g & 1) != 0;   // lane bit 4
+      const float s0 = up ? c0_ : c2_, s1 = up ? c1_ : c3_;
+      const float k0 = up ? c2_ : c0_, k1 = up ? c3_ : c1_;
+      c0 = k0 + lane_xor<16>(s0, lane);
+      c1 = k1 + lane_xor<16>(s1, lane);
+    }
+    {
+      const bool up = (g & 2) != 0;   // lane bit 5
+      const float send = up ? c0 : c1;
+      const float keep = up ? c1 : c0;
+      c0 = keep + lane_xor<32>(send, lane);
+    }
+    atomicAdd(&ws[J * WT + 4 * q + 2 * (g & 1) + (g >> 1)], c0);   // column 4 q + 2 (g & 1) + (g >> 1)
+  }
+}
+#endif
+
 #ifdef DSS_EIGS_PLAIN_LOADS   // lab: W through the default cache policy instead of the streaming (nt) one
 #define DSS_W_LOAD(p) (*(p))
 #else
@@ -284,6 +354,73 @@ DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* x
     side();
     DSS_ETL_WAVE_ADD(11)   // cycles of the check (its wave)
   }
+#ifndef DSS_EIGS_SIMPLE_STREAM   // lab: -DDSS_EIGS_SIMPLE_STREAM keeps the one-buffer loop below for 16-bit W too
+  if constexpr (sizeof(WE) == 2) {
+    {   // a fresh scalar copy of the tile base: its live range is this loop, not the whole solver (which would have it
+        // spilled and reloaded per tile - a scratch reload shares vmcnt with the tile loads and drains them)
+      asm volatile("" : "+s"(Wp));
+    }
+    // 16-bit W: TWO tiles of raw words per wave - while one is reduced, the loads of the wave's next tile are in flight.
+    // The per-row-group arithmetic is one opaque asm block (4 conversions, row partial, 4 column partials): left to
+    // itself hipcc converts all 64 words of a tile before the first product, and the 64 extra live registers are what
+    // made every earlier double-buffered variant spill (profiles/r03_eigs_lab.txt).
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) u32x2* gptr_t;   // global: the laundered pointer must not go flat
+    const gptr_t Wg = (gptr_t)(const void*)Wp;
+    const auto load_tile = [&](u32x2 (&raw)[16], int t) {
+      const gptr_t At = Wg + (size_t)t * (WT * WT / 4) + lane;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) raw[k] = DSS_W_LOAD(At + k * 64);
+    };
+    const auto reduce_tile = [&](const u32x2 (&raw)[16], int t, u32x2 (&next)[16]) {
+      while (t >= row_start + (nt - I)) { row_start += nt - I; ++I; }
+      const int J = I + (t - row_start);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // lane-derived addresses are RECOMPUTED per tile (a few VALU ops), not kept live
+      const f32x4 xj = *reinterpret_cast<const f32x4*>(xs + J * WT + 4 * (ln & 15));
+      const float* xi_base = xs + I * WT + (ln >> 4);
+      float rp[16];
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float xi = xi_base[4 * k];
+        float a0, a1, a2, a3;
+#ifdef DSS_EIGS_ABL_NOMATH   // lab: the W stream without its arithmetic (results are garbage)
+        rp[k] = __builtin_bit_cast(float, raw[k][0] ^ raw[k][1]) * xi * xj[0];
+        if (false)
+#endif
+        asm volatile(
+            "v_cvt_f32_u32_sdwa %1, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+            "v_cvt_f32_u32_sdwa %2, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+            "v_cvt_f32_u32_sdwa %3, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+            "v_cvt_f32_u32_sdwa %4, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+            "v_mul_f32 %0, %1, %11\n\t"
+            "v_fmac_f32 %5, %1, %15\n\t"
+            "v_fmac_f32 %0, %2, %12\n\t"
+            "v_fmac_f32 %6, %2, %15\n\t"
+            "v_fmac_f32 %0, %3, %13\n\t"
+            "v_fmac_f32 %7, %3, %15\n\t"
+            "v_fmac_f32 %0, %4, %14\n\t"
+            "v_fmac_f32 %8, %4, %15"
+            : "=&v"(rp[k]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+            : "v"(raw[k][0]), "v"(raw[k][1]), "v"(xj[0]), "v"(xj[1]), "v"(xj[2]), "v"(xj[3]), "v"(xi));
+        // the wave's next tile goes out once a quarter of this one is consumed: 24 + 32 raw pairs live instead of 32 + 32
+        if (k == 3 && t + stream_waves < ntiles) load_tile(next, t + stream_waves);
+      }
+      matvec_finish_tile(rp, c0, c1, c2, c3, I, J, ln, ws);
+    };
+    u32x2 r0[16], r1[16];
+    int t = (split && DSS_WAVE == stream_waves) ? ntiles : DSS_WAVE;
+    if (t < ntiles) load_tile(r0, t);
+    while (t < ntiles) {
+      reduce_tile(r0, t, r1);
+      t += stream_waves;
+      if (t >= ntiles) break;
+      reduce_tile(r1, t, r0);
+      t += stream_waves;
+    }
+  } else
+#endif
   for (int t = (split && DSS_WAVE == stream_waves) ? ntiles : DSS_WAVE; t < ntiles; t += stream_waves) {
     while (t >= row_start + (nt - I)) { row_start += nt - I; ++I; }
     const int J = I + (t - row_start);
