@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--parity-images", type=int, default=32,
                     help="images whose GPU eigenvectors are checked against the CPU oracle (the first --cpu-images of them "
                          "are the timed CPU baseline; 0 = only those)")
+    ap.add_argument("--host-pin", choices=("register", "malloc"), default="malloc",
+                    help="how the host image pool / result buffers are page-locked (see page_lock)")
     ap.add_argument("--distinct", type=int, default=1000,
                     help="distinct synthetic images generated per rank (BASELINE.json configs[1]: 1k synthetic images)")
     ap.add_argument("--dino-like-steps", type=int, default=1,
@@ -218,6 +220,22 @@ class ImageFeeder:
         ev = torch.cuda.Event()
         ev.record()
         self.free[c % self.NBUF] = ev
+
+
+def page_lock(t: torch.Tensor, how: str = "malloc") -> torch.Tensor:
+    """Page-locks a host tensor for the copy engine.  "malloc" (default): torch's own pinned allocation
+    (`tensor.pin_memory()`, hipHostMalloc).  "register": `hipHostRegister` on the tensor's ordinary pages.  Measured on
+    the driver's boxes, both ways round: SMALL copies (0.69 MB) out of registered /dev/shm pages take 0.024 ms against
+    1.33 ms out of hipHostMalloc memory (scripts/debug/shm_bench.py - what the CLI's worker path uses), but the bench's
+    48-200 MB chunk copies out of a registered numpy-allocated pool ran SLOWER (224 x 224: 13.7 k vs 34.3 k images/s;
+    480 x 480: 10 971 vs 10 935) - so the pool stays on hipHostMalloc."""
+    if how == "malloc":
+        return t.pin_memory()
+    t = t.contiguous()
+    rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+    if int(rc) != 0 or not t.is_pinned():
+        raise SystemExit(f"[bench] hipHostRegister failed ({rc}); run with --host-pin malloc")
+    return t
 
 
 def chunk_counts(cnt: int, vit_batch: int):
@@ -375,7 +393,7 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
     Returns (elapsed seconds, host seconds inside the loop, info tensors, gathered (meta, payload) or None, chunks used)."""
     dev = model.device
     width = a.K * n_patches + a.K
-    host_out = torch.empty((len(counts), max(counts), width), dtype=torch.float32, pin_memory=True)
+    host_out = page_lock(torch.empty((len(counts), max(counts), width), dtype=torch.float32), a.host_pin)
     copy_stream = torch.cuda.Stream(device=dev)
     infos, metas, flats = [], [], []
     if world > 1:
@@ -473,7 +491,8 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:   # numpy releases the GIL: ~40 ms/image serial
         host = torch.from_numpy(np.stack(list(ex.map(lambda i: synthetic.synthetic_image(rank + world * i, a.size, a.size),
-                                                     range(n_distinct))))).pin_memory()
+                                                     range(n_distinct)))))
+    host = page_lock(host, a.host_pin)
     feeder = ImageFeeder(host, a.vit_batch, dev, resident=a.resident)
     chunk_pos = 0                        # global chunk counter: every warm-up / timed step consumes its own chunks
 
@@ -577,7 +596,7 @@ def main():
                                     "fp32": "exact fp32 MFMA"}[os.environ.get("DSS_AFFINITY", "fused")],
                        "w_dtype": "u16-fixed (round(65535 w))" if a.w_dtype == "u16" else "f32",
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
-                       "h2d_in_timed_region": not a.resident,
+                       "h2d_in_timed_region": not a.resident, "host_page_lock": "hipHostRegister" if a.host_pin == "register" else "hipHostMalloc (tensor.pin_memory)",
                        "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
                        "stage_overlap": a.overlap, "gelu": a.gelu},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
