@@ -41,12 +41,14 @@ if __package__ in (None, ""):  # executed as a script: make the package importab
     sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
     import dss_amd  # noqa: F401
     from dss_amd import extract_utils as utils
+    from dss_amd import pthfast
     from dss_amd import spectral
     from dss_amd.distributed import init_process_group, rank_world, local_device
     from dss_amd import extract as _pkg   # worker processes resolve their entry points in the PACKAGE module
 else:
     _pkg = sys.modules[__name__]
     from . import extract_utils as utils
+    from . import pthfast
     from . import spectral
     from .distributed import init_process_group, rank_world, local_device
 
@@ -363,8 +365,6 @@ def _iter_features(files, which_features: str, processes: int, window: int, devi
         with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:
             yield from _bounded_map(pool, lambda f: _load_features(str(f), which_features), files, window)
         return
-    from . import pthfast
-
     per = 16
     chunks = [[str(f) for f in files[s:s + per]] for s in range(0, len(files), per)]
     biggest = max(os.path.getsize(f) for f in files)    # a file's size bounds its f32 feature bytes
@@ -400,8 +400,6 @@ def _iter_images(dataset, todo, processes: int, window: int, device: torch.devic
         with ThreadPoolExecutor(max_workers=_IO_THREADS) as pool:  # decode pool (the reference: 8 loader processes)
             yield from _bounded_map(pool, decode, todo, window)
         return
-    from . import pthfast
-
     per = 16
     names = [dataset.filenames[i] for i, _ in todo]
     paths = [str(n if dataset.root is None else dataset.root / n) for n in names]

@@ -428,6 +428,18 @@ def test_cli_worker_process_io_matches_the_in_process_path(tmp_path, monkeypatch
     monkeypatch.setenv("DSS_IO_PROCESSES", "3")
     run("_procs")
     assert not list(Path("/dev/shm").glob(f"dss_{os.getpid()}_*")), "shared blocks left behind"
+    # the same worker-process path when extract.py runs as a SCRIPT (no parent package: `python extract.py extract_eigs`)
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    subprocess.run([sys.executable, str(repo / "deep-spectral-segmentation_amd" / "extract.py"), "extract_eigs",
+                    "--images_root", str(tmp_path / "images"), "--features_dir", str(tmp_path / "feat_procs"),
+                    "--output_dir", str(tmp_path / "eigs_script"), "--K", "4", "--batch_size", "16"],
+                   check=True, timeout=600, env=dict(os.environ, DSS_IO_PROCESSES="2", DSS_ASSUME_YES="1"))
+    for fa in sorted((tmp_path / "eigs_procs").iterdir()):
+        a = torch.load(fa, map_location="cpu", weights_only=True)
+        b = torch.load(tmp_path / "eigs_script" / fa.name, map_location="cpu", weights_only=True)
+        assert torch.allclose(a["eigenvectors"], b["eigenvectors"], atol=2e-5) and torch.allclose(a["eigenvalues"], b["eigenvalues"], atol=2e-5)
     for sub in ("feat", "eigs"):
         a_dir, b_dir = tmp_path / f"{sub}_threads", tmp_path / f"{sub}_procs"
         assert sorted(p.name for p in a_dir.iterdir()) == sorted(p.name for p in b_dir.iterdir()) and len(list(a_dir.iterdir())) == 41
