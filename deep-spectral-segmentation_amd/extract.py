@@ -276,6 +276,27 @@ class _ShmBlocks:
 
     def __init__(self, count: int, size: int):
         self.count, self.size, self.paths, self.maps, self.tensors = count, size, [], [], []
+        self._sweep_stale()
+
+    @staticmethod
+    def _sweep_stale():
+        """Blocks of runs that were killed before their ``finally`` (names carry the owner's pid): remove those whose
+        process is gone."""
+        try:
+            names = [n for n in os.listdir("/dev/shm") if n.startswith("dss_")]
+        except OSError:
+            return
+        for n in names:
+            try:
+                pid = int(n.split("_")[1])
+                os.kill(pid, 0)          # raises if no such process
+            except (ProcessLookupError, ValueError, IndexError):
+                try:
+                    os.unlink(os.path.join("/dev/shm", n))
+                except OSError:
+                    pass
+            except PermissionError:
+                pass                      # somebody else's live process
 
     def add(self) -> int:
         import mmap
