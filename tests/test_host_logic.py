@@ -182,8 +182,9 @@ def test_wave_filling_batch_picks_whole_waves_of_workgroups():
             assert eff >= base - 1e-9                                    # never worse than the plain target
 
 
-def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp_path):
-    """profiles/r02_pmc_traffic.json (what bench.py reads for roofline.traffic) must follow from the committed
+@pytest.mark.parametrize("rnd", ["r02", "r03"])
+def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp_path, rnd):
+    """profiles/rNN_pmc_traffic.json (what bench.py reads for roofline.traffic) must follow from the committed
     rocprofv3 counter summaries: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch."""
     import json
     import subprocess
@@ -191,10 +192,10 @@ def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp
 
     prof = REPO / "profiles"
     out = tmp_path / "traffic.json"
-    subprocess.run([sys.executable, str(REPO / "scripts" / "make_pmc_traffic.py"), str(prof / "r02_pmc_fetch.csv"),
-                    str(prof / "r02_pmc_write.csv"), str(prof / "r02_bench_n1.json"), str(out)], check=True,
+    subprocess.run([sys.executable, str(REPO / "scripts" / "make_pmc_traffic.py"), str(prof / f"{rnd}_pmc_fetch.csv"),
+                    str(prof / f"{rnd}_pmc_write.csv"), str(prof / f"{rnd}_bench_n1.json"), str(out)], check=True,
                    capture_output=True)
-    new, old = json.loads(out.read_text()), json.loads((prof / "r02_pmc_traffic.json").read_text())
+    new, old = json.loads(out.read_text()), json.loads((prof / f"{rnd}_pmc_traffic.json").read_text())
     assert new["config"] == old["config"]
     for key in ("attention", "layernorm", "laplacian_eigs", "affinity"):
         assert abs(new["kernels"][key]["hbm_bytes_per_launch"] - old["kernels"][key]["hbm_bytes_per_launch"]) < 1.0
