@@ -412,6 +412,22 @@ def test_eigs_edge_shapes_against_fp64(n, d, K):
                ext=(lam64, v64))
 
 
+@pytest.mark.parametrize("n,K,ncv", [(15, 3, 0), (33, 4, 13), (70, 6, 21), (200, 5, 17), (130, 12, 33), (900, 5, 19)])
+def test_eigs_odd_krylov_dimensions_against_fp64(n, K, ncv):
+    """Odd projected dimensions: the dummy index of the Jacobi pairing, in the wave-scope solve that runs beside the W
+    stream (convergence checks) and in the workgroup-scope one (end of a cycle, restarts with a small ncv); N = ncv is
+    the breakdown case.  Against dense fp64 on the same features."""
+    rng = np.random.default_rng(100 + n)
+    base = rng.normal(size=(n, 32)).astype(np.float32)       # the affinity kernels take feature dims that are multiples of 32
+    feats = base + 0.6 * rng.normal(size=(1, 32)).astype(np.float32)
+    lam64, v64 = spectral_ref.dense_f64_eigs(feats, min(n - 1, K + 6))
+    ev, vec, info = spectral.laplacian_eigs_from_features(torch.from_numpy(feats)[None].to(DEV), K, ncv=ncv,
+                                                          affinity_mode="split", retry=False)
+    assert info.item() > 0
+    check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v64[:K], lam64[:K], what=f"n{n}K{K}ncv{ncv}",
+               d=build_w64(feats)[1], ext=(lam64, v64))
+
+
 def test_eigs_rejects_bad_arguments_and_reports_nonconvergence():
     feats = torch.from_numpy(synthetic.synthetic_features("random", 900, 384, 201, (30, 30)))[None].to(DEV)
     with pytest.raises(ValueError):

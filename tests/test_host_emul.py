@@ -150,3 +150,20 @@ def test_kernel_logic_other_branches_match_reference_goldens(emul, path):
     values, vectors, info = run_emul(emul, feats, K, mode=mode, threshold=thr)
     assert info > 0, info
     check_mode_against_golden(g, values, vectors, path)
+
+
+@pytest.mark.parametrize("n,K,ncv", [(15, 3, 0), (33, 4, 13), (70, 6, 21), (200, 5, 17), (130, 12, 33)])
+def test_kernel_logic_odd_krylov_dimensions(emul, n, K, ncv):
+    """Odd projected dimensions exercise the dummy index of the Jacobi pairing (a pair whose partner does not exist is
+    the identity; 2x2 block updates skip its row and column), with and without restarts (small ncv) and in the breakdown
+    case N = ncv.  Against dense fp64 on the same features."""
+    from oracle.spectral_ref import dense_f64_eigs
+
+    rng = np.random.default_rng(100 + n)
+    base = rng.normal(size=(n, 24)).astype(np.float32)
+    feats = base + 0.6 * rng.normal(size=(1, 24)).astype(np.float32)    # a common component: mostly positive affinities
+    k2 = min(n - 1, K + 6)
+    lam64, v64 = dense_f64_eigs(feats, k2)
+    lam, vec, info = run_emul(emul, feats, K, ncv=ncv)
+    assert info > 0, info
+    check_eigs(vec, lam, v64[:K], lam64[:K], what=f"n{n}_K{K}_ncv{ncv}", ext=(lam64, v64))
