@@ -10,10 +10,12 @@
 // restart with exact shifts for symmetric matrices) on S directly: no LU, no dense D, no dense L, and
 // each Lanczos step is one streaming pass over W.
 //
-// ONE WORKGROUP OWNS ONE IMAGE.  There is no inter-workgroup communication: 256 CUs advance 256 images
-// concurrently, every block-level step is a __syncthreads().  The dominant cost is streaming W from
-// HBM (4*N*ld bytes per Lanczos step; HBM-bound); everything else (reorthogonalisation against <= 64
-// basis vectors, the <= 64x64 Rayleigh-Ritz problem) is on-chip or L2-resident.
+// ONE WORKGROUP OWNS ONE IMAGE.  There is no inter-workgroup communication: two workgroups per CU advance 512 images
+// concurrently, every block-level step is a __syncthreads().  The dominant cost is streaming W from HBM (the stored
+// upper-triangular tiles, once per Lanczos step); everything else (reorthogonalisation against <= 64 basis vectors,
+// the <= 64x64 Rayleigh-Ritz problem) is on-chip or L2-resident.  The convergence check of a Lanczos state does not
+// stop the stream: the last wave of the workgroup solves the projected problem (WaveScope) while the other waves
+// stream W for the next step; a converged image is seen one pass late and that pass is discarded.
 //
 // The code below is written against a tiny "block" vocabulary (DSS_TID, DSS_NT, DSS_LANE, DSS_WAVE,
 // DSS_NWAVES, DSS_SYNC, DSS_WAVE_SUM, block_sum) so that the SAME source also compiles with g++ as a
