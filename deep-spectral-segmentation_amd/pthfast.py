@@ -9,7 +9,7 @@ module needs ``pickle``, ``zipfile``, ``mmap`` and numpy: a worker is up in ~0.3
 the three torch globals it contains, and reads the feature bytes of each file STRAIGHT INTO a block of ``/dev/shm`` that
 the parent has page-locked for the copy engine (disk cache -> block -> HBM, no other copy).
 
-Anything unexpected (compressed members, non-contiguous or non-float tensors, unknown pickled classes) is reported per
+Anything unexpected (compressed members, non-float features, unknown pickled classes) is reported per
 file; the parent then loads that file with ``torch.load`` itself.  Only ``tests/`` and ``extract.py`` import this."""
 from __future__ import annotations
 
@@ -106,11 +106,25 @@ class PthFile:
         return False
 
     def read_into(self, ref: TensorRef, out: memoryview) -> None:
-        """The elements of a CONTIGUOUS ``ref`` into ``out`` (exactly ``numel * itemsize`` bytes)."""
+        """The elements of ``ref`` in row-major order into ``out`` (exactly ``numel * itemsize`` bytes).  A contiguous
+        tensor is read straight from the archive member; a strided VIEW (what the reference saves when it runs on the
+        CPU: ``k`` is a slice of the whole qkv activation, extract/extract.py:96-98, and ``torch.save`` stores that
+        storage) is gathered from the member's bytes."""
         info = self.zip.getinfo(f"{self.prefix}data/{ref.key}")
-        if info.compress_type != zipfile.ZIP_STORED or not ref.is_contiguous():
-            raise Unsupported("compressed member or strided tensor")
+        if info.compress_type != zipfile.ZIP_STORED:
+            raise Unsupported("compressed member")
         nbytes = ref.numel * ref.dtype.itemsize
+        if not ref.is_contiguous():
+            if any(st < 0 for st in ref.stride) or ref.numel == 0:
+                raise Unsupported("strided tensor with negative strides")
+            last = ref.offset + sum((sz - 1) * st for sz, st in zip(ref.size, ref.stride))
+            if (last + 1) * ref.dtype.itemsize > info.file_size:
+                raise Unsupported("strided tensor outside its storage")
+            store = np.frombuffer(self.zip.read(info), dtype=ref.dtype)
+            view = np.lib.stride_tricks.as_strided(store[ref.offset:], shape=ref.size,
+                                                   strides=tuple(st * ref.dtype.itemsize for st in ref.stride))
+            np.frombuffer(out, dtype=ref.dtype, count=ref.numel).reshape(ref.size)[...] = view
+            return
         with self.zip.open(info) as fh:
             skip = ref.offset * ref.dtype.itemsize
             if skip:

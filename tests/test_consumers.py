@@ -476,8 +476,8 @@ def test_bbox_clusters_and_semantic_segmentations_match_reference(tmp_path, run)
 
 def test_pthfast_reads_feature_files_without_torch_semantics_lost(tmp_path):
     """The torch-free reader of the extract_eigs loader processes against torch.load on the reference's feature schema
-    (extract/extract.py:98-110), including half features, a strided tensor (reported, not mis-read) and a foreign
-    pickled class (reported)."""
+    (extract/extract.py:98-110), including half features, the strided qkv view a CPU run of the reference saves, a
+    non-float tensor (reported, not mis-read) and a foreign pickled class (reported)."""
     import mmap
     import os
 
@@ -493,28 +493,38 @@ def test_pthfast_reads_feature_files_without_torch_semantics_lost(tmp_path):
         torch.save({"k": k, "indices": torch.tensor(7 + i), "file": f"im{i}.jpg", "id": f"im{i}", "model_name": "dino_vits16",
                     "patch_size": 16, "shape": (1, 3, 96, 128)}, f)
         files.append((str(f), k))
+    # what the reference saves when it runs on the CPU (extract/extract.py:96-98): k is a strided view into the whole
+    # qkv activation [B, T, 3, h, dh] - CLS row dropped, the K third of every token row - and torch.save stores that storage
+    qkv = torch.randn(1, 1 + 20, 3 * 6 * 8)
+    k_view = qkv.reshape(1, 21, 3, 6, 8).permute(2, 0, 3, 1, 4)[1].transpose(1, 2).reshape(1, 21, -1)[:, 1:, :]
+    assert not k_view.is_contiguous() and k_view.shape == (1, 20, 48)
+    ref_like = tmp_path / "ref_like.pth"
+    torch.save({"k": k_view, "indices": torch.tensor(3), "file": "r.jpg", "id": "r", "model_name": "dino_vits16",
+                "patch_size": 16, "shape": (1, 3, 64, 80)}, ref_like)
+    files.append((str(ref_like), k_view.contiguous()))
     strided = tmp_path / "strided.pth"
-    torch.save({"k": torch.randn(1, 64, 48).transpose(1, 2), "file": "s.jpg", "patch_size": 16, "shape": (1, 3, 96, 128)}, strided)
+    torch.save({"k": torch.arange(64 * 48, dtype=torch.int32).reshape(1, 64, 48), "file": "s.jpg", "patch_size": 16,
+                "shape": (1, 3, 96, 128)}, strided)    # integer "features": not read here, reported
     foreign = tmp_path / "foreign.pth"
     torch.save({"k": torch.randn(1, 4, 4), "extra": np.arange(3), "file": "g.jpg", "patch_size": 16, "shape": (1, 3, 32, 32)}, foreign)
     block, size = tmp_path / "block", 1 << 20
     with open(block, "wb") as fh:
         fh.truncate(size)
     out = pthfast.load_chunk(str(block), size, [f for f, _ in files] + [str(strided), str(foreign)], "k")
-    assert len(out) == 5
+    assert len(out) == 6
     with open(block, "r+b") as fh:
         m = mmap.mmap(fh.fileno(), size)
     expect_off = 0
-    for (f, k), (meta, off, shape) in zip(files, out[:3]):
+    for (f, k), (meta, off, shape) in zip(files, out[:4]):
         assert off == expect_off and shape == tuple(k.shape[1:])
         got = np.frombuffer(m, dtype=np.float32, count=k.numel(), offset=off).reshape(shape)
         assert np.array_equal(got, k[0].float().numpy())
         ref = torch.load(f, weights_only=True)
         assert meta == {"indices": int(ref["indices"]), "file": ref["file"], "id": ref["id"], "model_name": ref["model_name"],
-                        "patch_size": 16, "shape": (1, 3, 96, 128)}
+                        "patch_size": 16, "shape": tuple(ref["shape"])}
         expect_off += 4 * k.numel()
-    assert out[3][0] is None and out[3][1] == str(strided) and "strided" in out[3][2]
-    assert out[4][0] is None and out[4][1] == str(foreign) and "numpy" in out[4][2]
+    assert out[4][0] is None and out[4][1] == str(strided) and "dtype" in out[4][2]
+    assert out[5][0] is None and out[5][1] == str(foreign) and "numpy" in out[5][2]
     # a block too small for the chunk: the overflow is reported per file, nothing is written past the end
     small = pthfast.load_chunk(str(block), 4 * 48 * 384 + 16, [files[0][0], files[1][0]], "k")
     assert small[0][0] is not None and small[1][0] is None and "block full" in small[1][2]
