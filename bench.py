@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--parity-images", type=int, default=32,
                     help="images whose GPU eigenvectors are checked against the CPU oracle (the first --cpu-images of them "
                          "are the timed CPU baseline; 0 = only those)")
-    ap.add_argument("--host-pin", choices=("register", "malloc"), default="malloc",
+    ap.add_argument("--host-pin", choices=("register", "malloc", "shm"), default="malloc",
                     help="how the host image pool / result buffers are page-locked (see page_lock)")
     ap.add_argument("--distinct", type=int, default=1000,
                     help="distinct synthetic images generated per rank (BASELINE.json configs[1]: 1k synthetic images)")
@@ -228,9 +228,12 @@ def page_lock(t: torch.Tensor, how: str = "malloc") -> torch.Tensor:
     the driver's boxes, both ways round: SMALL copies (0.69 MB) out of registered /dev/shm pages take 0.024 ms against
     1.33 ms out of hipHostMalloc memory (scripts/debug/shm_bench.py - what the CLI's worker path uses), but the bench's
     48-200 MB chunk copies out of a registered numpy-allocated pool ran SLOWER (224 x 224: 13.7 k vs 34.3 k images/s;
-    480 x 480: 10 971 vs 10 935) - so the pool stays on hipHostMalloc."""
+    480 x 480: 10 971 vs 10 935), and so did a registered /dev/shm segment ("shm": 13.4 k vs 36.3 k; 11 118 vs ~10 950) -
+    so the pool stays on hipHostMalloc."""
     if how == "malloc":
         return t.pin_memory()
+    if how == "shm":      # a /dev/shm segment (what the CLI's worker path copies out of), then registered
+        t = t.contiguous().clone().share_memory_()
     t = t.contiguous()
     rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
     if int(rc) != 0 or not t.is_pinned():
@@ -596,7 +599,7 @@ def main():
                                     "fp32": "exact fp32 MFMA"}[os.environ.get("DSS_AFFINITY", "fused")],
                        "w_dtype": "u16-fixed (round(65535 w))" if a.w_dtype == "u16" else "f32",
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
-                       "h2d_in_timed_region": not a.resident, "host_page_lock": "hipHostRegister" if a.host_pin == "register" else "hipHostMalloc (tensor.pin_memory)",
+                       "h2d_in_timed_region": not a.resident, "host_page_lock": {"register": "hipHostRegister", "shm": "hipHostRegister on a /dev/shm segment", "malloc": "hipHostMalloc (tensor.pin_memory)"}[a.host_pin],
                        "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
                        "stage_overlap": a.overlap, "gelu": a.gelu},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
