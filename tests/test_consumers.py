@@ -529,3 +529,44 @@ def test_pthfast_reads_feature_files_without_torch_semantics_lost(tmp_path):
     small = pthfast.load_chunk(str(block), 4 * 48 * 384 + 16, [files[0][0], files[1][0]], "k")
     assert small[0][0] is not None and small[1][0] is None and "block full" in small[1][2]
     assert "torch" not in pthfast.__dict__
+
+
+def test_worker_process_pump_runs_without_a_gpu(tmp_path, monkeypatch):
+    """`extract._pump_chunks` - torch-free loader processes filling /dev/shm blocks, block recycling in chunk order - with
+    the stream events it uses on a GPU replaced by no-ops: every file's feature rows come back intact, in order, through
+    fewer blocks than there are chunks."""
+    import numpy as np
+    import torch
+
+    from dss_amd import extract, pthfast
+
+    class _NoEvent:
+        def record(self):
+            pass
+
+        def synchronize(self):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "Event", _NoEvent)
+    files, want = [], []
+    for i in range(37):
+        n = 20 + (i % 3)          # mixed shapes inside a chunk
+        k = torch.randn(1, n, 16)
+        f = tmp_path / f"{i:03d}.pth"
+        torch.save({"k": k, "indices": torch.tensor(i), "file": f"{i:03d}.jpg", "id": f"{i:03d}", "model_name": "m",
+                    "patch_size": 16, "shape": (1, 3, 64, 80)}, f)
+        files.append(str(f)), want.append(k[0].numpy().copy())
+    chunks = [files[s:s + 4] for s in range(0, len(files), 4)]     # 10 chunks through 2 + 2 blocks
+    got, blocks_seen = [], set()
+    for entries, block, release in extract._pump_chunks(pthfast.load_chunk, chunks, ("k",), 2, 4 * 4096):
+        blocks_seen.add(block.data_ptr())
+        for meta, off, shape in entries:
+            assert meta is not None, (off, shape)
+            rows = block[off:off + 4 * shape[0] * shape[1]].view(torch.float32).view(shape).clone()
+            got.append((meta["indices"], rows.numpy()))
+        release()
+    assert [i for i, _ in got] == list(range(37)) and len(blocks_seen) <= 4
+    for (i, rows), ref in zip(got, want):
+        assert np.array_equal(rows, ref), i
+    import os
+    assert not [n for n in os.listdir("/dev/shm") if n.startswith(f"dss_{os.getpid()}_")]
