@@ -239,6 +239,34 @@ def make_feature_goldens(ref):
                         sizes=np.array([(h, w) for _, h, w in FEATURE_IMAGES]), **out)
 
 
+def make_feature_file_fixture(ref):
+    """The reference's OWN on-disk feature file, byte for byte: ``extract_features`` (extract/extract.py:21-116) run on
+    one tiny image, its ``<id>.pth`` copied to tests/golden/ref_feature_file.pth.  On the CPU the saved ``k`` is a strided
+    view into the whole qkv activation (extract.py:96-98: reshape / permute / slice, then ``.cpu()`` of a CPU tensor is
+    a no-op) and ``torch.save`` stores that storage - the layout the torch-free reader of the CLI's loader processes
+    (``pthfast``) has to understand."""
+    import shutil
+
+    from PIL import Image
+
+    sd = synthetic.synthetic_state_dict(FEATURE_MODEL, FEATURE_WEIGHT_SEED, FEATURE_LN_JITTER)
+    torch.hub.load = lambda repo, name, *a, **k: vit_ref.build_ref_vit(name, sd)
+    with tempfile.TemporaryDirectory() as tmp:
+        root, odir = Path(tmp) / "images", Path(tmp) / "features"
+        root.mkdir()
+        Image.fromarray(synthetic.synthetic_image(hash_name("tiny.png"), 52, 70)).save(root / "tiny.png")
+        lst = Path(tmp) / "images.txt"
+        lst.write_text("tiny.png\n")
+        ref.extract_features(images_list=str(lst), images_root=str(root), model_name=FEATURE_MODEL,
+                             batch_size=1, output_dir=str(odir))
+        src = odir / "tiny.pth"
+        dct = torch.load(src, map_location="cpu", weights_only=False)
+        k = dct["k"]
+        print(f"[golden] reference feature file: k{tuple(k.shape)} strides {k.stride()} offset {k.storage_offset()} "
+              f"contiguous={k.is_contiguous()} storage elements {k.untyped_storage().nbytes() // 4}, {src.stat().st_size} B")
+        shutil.copy(src, GOLDEN / "ref_feature_file.pth")
+
+
 def hash_name(fn: str) -> int:
     """Stable image index from a file name (so duplicates regenerate the same image)."""
     return sum(ord(c) for c in fn) % 1000
@@ -729,7 +757,8 @@ def main():
         check_vit_against_hf()  # before the stubs: transformers probes for a real torchvision
     ref = _import_reference()
     only = set(sys.argv[1:])  # e.g. `python oracle/make_golden.py eigs modes`; nothing = everything
-    steps = {"probe": make_index_probe, "features": make_feature_goldens, "eigs": make_eig_goldens,
+    steps = {"probe": make_index_probe, "features": make_feature_goldens, "feature_file": make_feature_file_fixture,
+             "eigs": make_eig_goldens,
              "single_region": make_single_region_golden, "modes": make_mode_goldens,
              "consumers": make_consumer_goldens, "bbox_features": make_bbox_feature_golden, "color": make_color_goldens,
              "localization": make_localization_golden, "semantic": make_semantic_golden}

@@ -570,3 +570,33 @@ def test_worker_process_pump_runs_without_a_gpu(tmp_path, monkeypatch):
         assert np.array_equal(rows, ref), i
     import os
     assert not [n for n in os.listdir("/dev/shm") if n.startswith(f"dss_{os.getpid()}_")]
+
+
+def test_pthfast_reads_the_reference_written_feature_file(tmp_path, golden_dir):
+    """tests/golden/ref_feature_file.pth is the file the REFERENCE's extract_features wrote on the CPU (made by
+    `oracle/make_golden.py feature_file`): `k` is a strided view of the whole qkv activation.  The torch-free reader
+    must return exactly what torch.load returns, and the loader entry point what `_load_features` returns."""
+    import mmap
+
+    import numpy as np
+    import torch
+
+    from dss_amd import extract, pthfast
+
+    path = golden_dir / "ref_feature_file.pth"
+    ref = torch.load(path, map_location="cpu", weights_only=True)
+    assert not ref["k"].is_contiguous() and ref["k"].shape == (1, 12, 384)      # what this fixture is for
+    with pthfast.PthFile(str(path)) as f:
+        got = f.read(f.obj["k"])
+        assert f.obj["file"] == ref["file"] and f.obj["patch_size"] == 16 and tuple(f.obj["shape"]) == tuple(ref["shape"])
+    assert np.array_equal(got, ref["k"].numpy())
+    block, size = tmp_path / "block", 1 << 16
+    with open(block, "wb") as fh:
+        fh.truncate(size)
+    (meta, off, shape), = pthfast.load_chunk(str(block), size, [str(path)], "k")
+    _, feats = extract._load_features(str(path), "k")
+    with open(block, "r+b") as fh:
+        m = mmap.mmap(fh.fileno(), size)
+    assert shape == (12, 384) and np.array_equal(np.frombuffer(m, dtype=np.float32, count=12 * 384, offset=off).reshape(shape),
+                                                 feats.numpy())
+    assert meta["id"] == ref["id"] and meta["indices"] == int(ref["indices"])

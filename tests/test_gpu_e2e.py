@@ -460,6 +460,30 @@ def test_cli_worker_process_io_matches_the_in_process_path(tmp_path, monkeypatch
                     assert a[key] == b[key], (fa.name, key)
 
 
+def test_extract_eigs_on_the_reference_written_feature_file(tmp_path, golden_dir, monkeypatch):
+    """tests/golden/ref_feature_file.pth was written by the REFERENCE's extract_features on the CPU (`k` is a strided view
+    of the whole qkv activation, extract/extract.py:96-98).  extract_eigs must take it through the in-process loader and
+    through the torch-free loader processes alike, and agree with the oracle on the loaded features."""
+    import shutil
+
+    if extract._shm_free_bytes() < (1 << 30):
+        pytest.skip("/dev/shm too small for the shared blocks of the worker-process path")
+    feat = tmp_path / "feat"
+    feat.mkdir()
+    shutil.copy(golden_dir / "ref_feature_file.pth", feat / "renamed.pth")
+    k = torch.load(golden_dir / "ref_feature_file.pth", map_location="cpu", weights_only=True)["k"]
+    lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(k.contiguous(), 3)
+    for tag, procs in (("threads", "0"), ("procs", "2")):
+        monkeypatch.setenv("DSS_IO_PROCESSES", procs)
+        extract.main(["extract_eigs", "--images_root", "", "--features_dir", str(feat), "--output_dir",
+                      str(tmp_path / f"eigs_{tag}"), "--K", "3"])
+        out = sorted((tmp_path / f"eigs_{tag}").iterdir())
+        assert [p.name for p in out] == ["tiny.pth"]       # the reference names the output after data_dict['file'] (:141)
+        ed = torch.load(out[0], map_location="cpu", weights_only=True)
+        check_eigs(ed["eigenvectors"].numpy(), ed["eigenvalues"].numpy(), v.numpy(), lam.numpy(), what=tag,
+                   d=build_w64(k[0].numpy())[1], ext=ext)
+
+
 def test_cli_two_ranks_shard_round_robin(tmp_path):
     """N>1 on the real kernels: two processes (sharing this box's single GPU; gloo for the barriers) run the two
     CLI stages; together they must produce exactly the single-process outputs, each file written once."""
