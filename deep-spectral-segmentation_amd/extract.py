@@ -854,6 +854,7 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     with clock("start savers"):
         saver = _AsyncSaver(processes=min(nproc, 4))
     loaded = _iter_features(mine, which_features, nproc, 4 * bs, device)
+    scheduled = set()
     while True:
         with clock("wait for loaded features"):
             nxt = next(loaded, None)
@@ -862,9 +863,12 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         data_dict, feats = nxt
         image_id = data_dict["file"][:-4]
         output_file = str(Path(output_dir) / f"{image_id}.pth")
-        if Path(output_file).is_file():
+        # the reference writes synchronously, so a second feature file naming the same image finds the first one's
+        # output and is skipped (extract.py:141-146); here the first may still be in flight: remember what is scheduled
+        if output_file in scheduled or Path(output_file).is_file():
             print(f"Skipping existing file {str(output_file)}")
             continue
+        scheduled.add(output_file)
         problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
                                      data_dict["patch_size"])
         utils.get_image_sizes(data_dict)
