@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--min-warmup-seconds", type=float, default=4.0,
                     help="keep running untimed warm-up steps (beyond --warmup) until this much wall time has passed: "
                          "the first GPU process on a fresh box runs ~20 %% slower until clocks/power have ramped")
+    ap.add_argument("--linear-kres", type=int, default=2, choices=[0, 1, 2],
+                    help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
+    ap.add_argument("--no-fuse-ln", action="store_true",
+                    help="A/B arm: standalone residual + LayerNorm passes instead of the fused dss_lnlinear_* prologue")
     ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
                     help="erf = DINO's GELU (default, the reported configuration); tanh_fused = hipBLASLt epilogue "
                          "(tanh approximation, NOT the reference function; diagnostic only)")
@@ -306,12 +310,16 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
                 byts = (4.0 * m["n"] * m["d"] + m.get("w_bytes", 4) / 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        elif name == "linear_kres":
-            # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input)
+        elif name in ("linear_kres", "lnlinear", "library_gemm"):
+            # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input); the fused
+            # residual + LayerNorm + Linear kernel additionally reads x f32 + the pending branch output and writes x back
             flops = np.mean([2.0 * m["m"] * m["n"] * m["k"] for m in metas])
             outb = np.mean([2.0 * m["m"] * m["n"] for m in metas])
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s",
                          output_GBs=round(outb / (avg * 1e-3) / 1e9, 1))
+            if name == "lnlinear":
+                hbm = np.mean([m["m"] * m["k"] * (10.0 if m["res"] else 4.0) + 2.0 * m["m"] * m["n"] for m in metas])
+                entry["hbm_GBs"] = round(hbm / (avg * 1e-3) / 1e9, 1)
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
@@ -466,7 +474,7 @@ def main():
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
-    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu)
+    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -570,13 +578,14 @@ def main():
     n_unconverged = int((info_all <= 0).sum().item())
     if rank == 0:
         kern = summarize_timers(timers, n_patches, dim, depth)
-        dominant = max((k for k in kern if "achieved" in kern[k]), key=lambda k: kern[k]["total_ms"])
+        dominant = max((k for k in kern if "achieved" in kern[k] and k != "library_gemm"), key=lambda k: kern[k]["total_ms"])
+        n_forwards = sum(len(chunk_counts(c, a.vit_batch)) for c in counts)
         d = kern[dominant]
         traffic = pmc_traffic(dominant, a)  # HBM bytes per launch from the committed rocprofv3 PMC passes, or None
+        steps_out = len(counts)
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"], "traffic": traffic[0] if traffic else None,
                     "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE)*1024", "traffic_source": traffic[1] if traffic else None}
-        steps_out = len(counts)
         out = {
             "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
             "value": round(n_images / elapsed, 2), "unit": "images/s",
@@ -604,6 +613,11 @@ def main():
                        "stage_overlap": a.overlap, "gelu": a.gelu},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
+            # what is NOT a hand-written kernel, and what the fused prologue removed: standalone LayerNorm launches per ViT
+            # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
+            "layernorm_launches_per_forward": round(kern.get("layernorm", {}).get("launches", 0) / max(n_forwards, 1), 2),
+            "library_gemm_ms_per_step": round(kern.get("library_gemm", {}).get("total_ms", 0.0) / steps_out, 3),
+            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln},
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
             "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
@@ -621,7 +635,8 @@ def main():
     if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
-        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu)
+        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
+                     fuse_ln=not a.no_fuse_ln)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

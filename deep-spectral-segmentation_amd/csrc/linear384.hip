@@ -28,8 +28,19 @@
 //   * bias is the accumulators' initial value; GELU is exact-erf by Abramowitz-Stegun 7.1.28
 //     (erf z = 1 - (1 + a1 z + .. + a6 z^6)^-16, |error| <= 3e-7: one v_rcp, no v_exp), written on float2 so the
 //     polynomial runs on v_pk_fma_f32 / v_pk_mul_f32.
+//   * round 4: the LayerNorm in front of qkv / fc1 (and the residual add in front of IT) is the kernel's A prologue
+//     (dss_lnlinear_k384 / _k768, LNM != 0 below): the standalone pass read x f32 + the pending branch output, wrote x f32
+//     + h f16, and this kernel read h again - 23 launches of 1.2 GB per forward that only re-read what a wave is about to
+//     hold.  Here a wave walks its RT x K/32 UNITS of 32 rows x 32 columns: x arrives by LDS-DMA as full 128-byte lines
+//     (4 KB per unit, a ring of slots in the - still idle - W double buffer), the residual tile (32 rows x 64 columns of
+//     f16: two units) in the wave's transpose patch; the lane reads its fragment-shaped share, adds, accumulates
+//     pivot-shifted first and second moments of ITS two rows (a lane owns whole half rows: no butterfly, one lane^32
+//     exchange at the end), packs the raw sum into the resident A fragments, writes the f32 sums back into the slot and
+//     stores them as full lines; when the statistics are complete the fragments are normalised in place
+//     ((a - mean) rstd: gamma and beta are folded into W and bias by the caller).
 #include "common.h"
 #include "kres.h"
+#include <utility>
 
 // scripts/probes/linear_lab.hip includes this file with DSS_LIN_TIMELINE defined: wave 0 of every workgroup adds the shader
 // cycles it spends in the A prologue, the MFMA phases, the epilogues and the end-of-chunk wait + barrier to dss_lin_tl.
@@ -48,6 +59,38 @@ namespace dss {
 
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
 static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// Issue order of the vector-memory instructions of the LayerNorm prologue (every event below is 4 instructions of one
+// wave; gfx9 retires loads, LDS-DMA and stores through ONE in-order vmcnt):  Pt(0), X(0..NXS-1), Pt(1);  then after unit
+// v has been processed: ST(v) [the x write-back], X(v + NXS), and behind an odd v the residual tile Pt(v/2 + 2).
+// after(u) = instructions issued behind the younger of X(u) / Pt(u/2) when unit u is waited for = its s_waitcnt vmcnt.
+template <int NUNIT, int NXS, bool RES> struct LnSched {
+  static constexpr int after(int u) {
+    int n = 0, px[64] = {}, pp[40] = {};
+    if (RES) { pp[0] = n; n += 4; }
+    for (int i = 0; i < NXS && i < NUNIT; ++i) { px[i] = n; n += 4; }
+    if (RES && NUNIT > 2) { pp[1] = n; n += 4; }
+    for (int v = 0; v < NUNIT; ++v) {
+      if (v == u) {
+        int last = px[u];
+        if (RES && pp[u >> 1] > last) last = pp[u >> 1];
+        return n - (last + 4);
+      }
+      if (RES) n += 4;
+      if (v + NXS < NUNIT) { px[v + NXS] = n; n += 4; }
+      if (RES && (v & 1) && (v >> 1) + 2 < NUNIT / 2) { pp[(v >> 1) + 2] = n; n += 4; }
+    }
+    return 0;
+  }
+};
 
 // KS = K / 16 MFMA k-steps held per token row; RT = 32-row tiles per wave.  KS * RT = 48 fragments = 192 VGPRs.
 // NW = waves per workgroup.  K = 384: FOUR waves (one per SIMD) and 80 KB of LDS - TWO workgroups share a CU, the SIMD's two
@@ -71,10 +114,14 @@ template <int KS, int RT, int NW> struct LinCfg {
   static constexpr int NSTORE = 4 * RT;                     // 16-byte stores per lane per finished 64-column group
 };
 
-template <class T, bool GELU, int KS, int RT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(const T* __restrict__ A, const T* __restrict__ W,
-                                                                 const T* __restrict__ bias, T* __restrict__ C,
-                                                                 int M, int N, int planar) {
+// LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
+// res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
+template <class T, bool GELU, int KS, int RT, int NW, int LNM>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
+                                                                 const T* __restrict__ R, long r_ld, long r_plane, float eps,
+                                                                 const T* __restrict__ W,
+                                                                 const T* __restrict__ bias, const float* __restrict__ aux,
+                                                                 T* __restrict__ C, int M, int N, int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
   typedef LinCfg<KS, RT, NW> Cfg;
@@ -96,7 +143,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   // (li, hh) 16 bytes of row li, a wave-instruction touching 32 rows x 32 B, 1536 partial-line requests per wave where 384
   // full lines do; measured equal in time (see LinCfg), kept for the 4x fewer L2 requests.
   V8 a[RT][LKS];
-  {
+  float am[RT];                                            // LNM != 0: A side of the correction k-step (mean | sigma), per row tile
+  if constexpr (LNM == 0) {
     typedef __attribute__((address_space(3))) void* lds3_t;
     const unsigned long long abase = (unsigned long long)(A + (long)blockIdx.x * LBM * LK);
     const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)abase), ahi = __builtin_amdgcn_readfirstlane((unsigned)(abase >> 32));
@@ -139,6 +187,137 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
           a[t][4 * rd + sl] = *reinterpret_cast<const V8*>(pw + (32 * t + li) * 128 + ((((unsigned)(2 * sl + hh)) ^ fsw) << 4));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers before the next round lands
     }
+  } else {
+    // ---- LayerNorm prologue: x (+= res) -> statistics -> normalised A fragments (see the file header) ---------------------
+    typedef __attribute__((address_space(3))) void* lds3_t;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    constexpr bool RES = LNM == 2;
+    constexpr int NCB = LK / 32, NUNIT = RT * NCB;          // 32-column blocks per row, units per wave
+    constexpr int WS_SHARE = 2 * Cfg::CHUNK_BYTES / LWAVES;  // this wave's share of the idle W double buffer: 12 KB
+    constexpr int NSLOT = (WS_SHARE + Cfg::PATCH_BYTES) / 4096;
+    constexpr int NXS = RES ? NSLOT - 2 : NSLOT;             // x slots (K = 384: 3 / 5; K = 768: 2 / 4); 2 residual slots
+    static_assert(WS_SHARE % 4096 == 0 && Cfg::PATCH_BYTES % 4096 == 0 && NXS >= 2 && NCB % 2 == 0 && NUNIT <= 48, "LN prologue layout");
+    typedef LnSched<NUNIT, NXS, RES> Sched;
+    unsigned char* const ws_share = &Ws[0][0] + wave * WS_SHARE;
+    unsigned char* const patch = &Stg[wave][0];
+    auto slot_ptr = [&](int i) -> unsigned char* { return i * 4096 < WS_SHARE ? ws_share + i * 4096 : patch + (i * 4096 - WS_SHARE); };
+    const size_t row0 = (size_t)blockIdx.x * LBM;
+    const unsigned char* const xblk = reinterpret_cast<const unsigned char*>(X) + row0 * (size_t)(LK * 4);
+    const unsigned char* const rblk = reinterpret_cast<const unsigned char*>(R) + row0 * (size_t)r_ld * 2;
+    const unsigned r_ldb = (unsigned)r_ld * 2u;
+    const unsigned fsw16 = 16u * (unsigned)((li >> 1) & 7);
+    // one DMA piece = 8 rows x 128 B: lane l -> row 8 q + (l >> 3), 16-byte chunk (l & 7) ^ swizzle(row) (source-side swizzle)
+    const int prow = lane >> 3;
+    const unsigned pch16[2] = {16u * (unsigned)((lane & 7) ^ (lane >> 4)), 16u * (unsigned)((lane & 7) ^ (4 + (lane >> 4)))};
+    auto dma = [&](unsigned lds_addr, unsigned voff, const unsigned char* sbase) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+    };
+    auto uniform_ptr = [&](const unsigned char* p) -> const unsigned char* {
+      const unsigned long long v = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto rowc = [&](int t, int q) { return (unsigned)min(rloc + 32 * t + 8 * q + prow, mrem - 1); };
+    auto issue_x = [&](int u) {                               // unit u = (t, cb): 32 rows x 32 columns of f32
+      const int t = u / NCB, cb = u % NCB;
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds3_t)slot_ptr(u % NXS));
+      const unsigned char* src = uniform_ptr(xblk + 128 * cb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma(dst + 1024u * q, rowc(t, q) * (unsigned)(LK * 4) + pch16[q & 1], src);
+    };
+    auto issue_p = [&](int j) {                               // residual tile j = (t, 64-column group): 32 rows x 128 B
+      const int t = (2 * j) / NCB, g = ((2 * j) % NCB) >> 1;
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds3_t)slot_ptr(NXS + (j & 1)));
+      const unsigned char* src = uniform_ptr(rblk + (size_t)g * (size_t)r_plane * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma(dst + 1024u * q, rowc(t, q) * r_ldb + pch16[q & 1], src);
+    };
+    float piv[RT], s1[RT], s2[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { piv[t] = 0.f; s1[t] = 0.f; s2[t] = 0.f; }
+    if (RES) issue_p(0);
+#pragma unroll
+    for (int i = 0; i < NXS && i < NUNIT; ++i) issue_x(i);
+    if (RES && NUNIT > 2) issue_p(1);
+    static_for<NUNIT>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int t = u / NCB, cb = u % NCB, o = cb & 1;
+      if (block_full) wait_vmcnt<Sched::after(u)>();
+      else wait_vmcnt<0>();                                   // a ragged block predicates its stores: unknown counts
+      unsigned char* xs = slot_ptr(u % NXS);
+      unsigned char* xr = xs + li * 128;
+      f32x4v v0[2], v1[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        v0[sl] = *reinterpret_cast<const f32x4v*>(xr + ((16u * (4 * sl + 2 * hh)) ^ fsw16));
+        v1[sl] = *reinterpret_cast<const f32x4v*>(xr + ((16u * (4 * sl + 2 * hh + 1)) ^ fsw16));
+      }
+      if constexpr (RES) {
+        const unsigned char* pr = slot_ptr(NXS + ((u >> 1) & 1)) + li * 128;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const V8 pv = *reinterpret_cast<const V8*>(pr + ((16u * (4 * o + 2 * sl + hh)) ^ fsw16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v0[sl][e] += to_f32<T>(pv[e]); v1[sl][e] += to_f32<T>(pv[4 + e]); }
+        }
+      }
+      if (cb == 0) piv[t] = v0[0][0];
+      float u1[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};            // this unit's moments: two short chains per k-step, not one of 32
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        V8 fr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = v0[sl][e] - piv[t], d1 = v1[sl][e] - piv[t];
+          u1[sl] += d0 + d1;
+          u2[sl] = fmaf(d0, d0, fmaf(d1, d1, u2[sl]));
+          fr[e] = from_f32<T>(v0[sl][e]);
+          fr[4 + e] = from_f32<T>(v1[sl][e]);
+        }
+        asm volatile("" : "+v"(fr));                           // packed HERE (hipcc otherwise carries the f32 values to the end)
+        a[t][2 * cb + sl] = fr;
+      }
+      s1[t] += u1[0] + u1[1];
+      s2[t] += u2[0] + u2[1];
+      asm volatile("" : "+v"(s1[t]), "+v"(s2[t]));             // ... and the moments are final HERE, not 20 units later
+      if constexpr (RES) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {                       // the sums go back into the slot (same lanes, same places) ...
+          *reinterpret_cast<f32x4v*>(xr + ((16u * (4 * sl + 2 * hh)) ^ fsw16)) = v0[sl];
+          *reinterpret_cast<f32x4v*>(xr + ((16u * (4 * sl + 2 * hh + 1)) ^ fsw16)) = v1[sl];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and leave as full lines: piece q = rows 8 q .. 8 q + 7
+        unsigned char* xw = const_cast<unsigned char*>(xblk) + 128 * cb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4v lin = *reinterpret_cast<const f32x4v*>(xs + 1024 * q + 16 * lane);
+          if (block_full || rloc + 32 * t + 8 * q + prow < mrem)
+            *reinterpret_cast<f32x4v*>(xw + rowc(t, q) * (unsigned)(LK * 4) + pch16[q & 1]) = lin;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is free: every LDS read of it has returned
+      if (u + NXS < NUNIT) issue_x(u + NXS);
+      if (RES && (u & 1) && (u >> 1) + 2 < NUNIT / 2) issue_p((u >> 1) + 2);
+    });
+    // statistics: this lane holds K/2 elements of each of its RT rows (pivot-shifted moments), lane ^ 32 the other half.
+    // The fragments stay RAW (f16(x): one rounding).  (x - mean) rstd never exists: with sw[col] = sum_k W[col][k] and
+    // sigma = 1 / rstd, out = rstd (acc_raw - mean sw[col] + sigma b[col]) - the bracket's two corrections are ONE fp32 MFMA
+    // (v_mfma_f32_32x32x2_f32: k = 0 multiplies -sw[col] with mean[row], k = 1 b[col] with sigma[row]; exact fp32
+    // products) where the plain kernel has its bias k-step, the table aux[col] = (-sw, b) is the caller's
+    // (dss_lnlinear_prepare); the epilogue multiplies by rstd.
+    constexpr float HN = (float)(LK / 2);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float mh = piv[t] + s1[t] * (1.0f / HN), m2h = fmaxf(s2[t] - s1[t] * s1[t] * (1.0f / HN), 0.f);
+      const float mo = __shfl_xor(mh, 32, 64), m2o = __shfl_xor(m2h, 32, 64);
+      const float mean = 0.5f * (mh + mo), dl = mo - mh;
+      const float var = (m2h + m2o + dl * dl * (0.5f * HN)) * (1.0f / (float)LK);
+      am[t] = hh ? (var + eps) * rsqrtf(var + eps) : mean;   // A side of the correction k-step: k = 0 mean, k = 1 sigma
+    }
+    __syncthreads();                                           // the W double buffer returns to its owner
   }
 
   // ---- W chunk staging by LDS-DMA: instruction j of wave w stages k-step s = NST w + j (64 lanes x 16 B = 1 KB):
@@ -186,7 +365,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
 
   // bias of this lane's column in the chunk, fetched one chunk ahead (a plain load: hipcc waits for it at its first use,
   // the START of the next chunk's MFMA phase, right behind wait_dma + barrier where nothing younger is in flight)
-  T bias_next = bias[li];
+  T bias_next = from_f32<T>(0.f);
+  if constexpr (LNM == 0) bias_next = bias[li];
   (void)LTHREADS;
 
   // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
@@ -216,7 +396,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
 #pragma unroll
     for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
     const float bcol = to_f32<T>(bias_next);
-    if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
+    float wcorr = 0.f;
+    if constexpr (LNM == 0) {
+      if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
+    } else {
+      // aux[col] = (-sw, b) of THIS chunk, needed by its last MFMA: requested here, awaited there by count (the NST pieces of the
+      // next W chunk are younger) - a value prefetched a chunk ahead would be a register held through the GELU epilogue,
+      // and so would its lane offset (rebuilt from v_mbcnt behind an opaque asm: 4 VALU per chunk)
+      unsigned l;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+      const unsigned aoff = ((l & 31u) << 3) | ((l >> 5) << 2);
+      const float* ap = aux + 2 * c * LBN;
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(wcorr) : "v"(aoff), "s"(ap) : "memory");
+    }
     if (stage_next >= 0) stage(stage_next);                // DMA issue behind the first fragment reads
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -233,19 +425,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);
       }
     }
-    V8 fb, a_one;
+    if constexpr (LNM == 0) {
+      V8 fb, a_one;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      fb[e] = from_f32<T>((e == 0 && hh == 0) ? bcol : 0.0f);
-      a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
+      for (int e = 0; e < 8; ++e) {
+        fb[e] = from_f32<T>((e == 0 && hh == 0) ? bcol : 0.0f);
+        a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
+      }
+      acc0 = mfma32x32x16(fb, a_one, acc0);
+      if (RT == 2) acc1 = mfma32x32x16(fb, a_one, acc1);
+    } else {
+      if (stage_next >= 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wcorr) : "n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcorr) :: "memory");
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcorr, am[0], acc0, 0, 0, 0);
+      if (RT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcorr, am[RT - 1], acc1, 0, 0, 0);
     }
-    acc0 = mfma32x32x16(fb, a_one, acc0);
-    if (RT == 2) acc1 = mfma32x32x16(fb, a_one, acc1);
     __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 32 RT rows x 128 B
   auto epilogue = [&](int c) {
+    if constexpr (LNM != 0) {                              // acc *= 1 / sigma, in place: sigma lives in the hh = 1 lane of the pair
+#pragma unroll                                             // (rstd kept per row tile would be registers the GELU does not have)
+      for (int t = 0; t < RT; ++t) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(am[t]), __float_as_uint(am[t]), false, false);
+        const unsigned sg = r[1];
+        const float rs = __builtin_amdgcn_rcpf(__uint_as_float(sg));
+        if (RT == 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { acc0[i] *= rs; acc1[i] *= rs; }
+        } else if (t == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc0[i] *= rs;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc1[i] *= rs;
+        }
+      }
+    }
 #if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 4)   // lab ablation: no epilogue at all (accumulators kept alive)
     asm volatile("" :: "v"(acc0), "v"(acc1));
     return;
@@ -312,34 +529,72 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   DSS_TL_FLUSH
 }
 
-template <class T, int KS, int RT, int NW>
-static void launch_linear_kres(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
-                               int planar, hipStream_t s) {
-  const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
-  if (gelu)
-    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A,
-                       (const T*)W, (const T*)bias, (T*)C, M, N, planar);
-  else
-    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A,
-                       (const T*)W, (const T*)bias, (T*)C, M, N, planar);
+// One wave per output column: Wg[n][k] = T(W[n][k] gamma[k]);  aux[n] = (-sum_k float(Wg[n][k]), bias[n] + sum_k W[n][k] beta[k])
+// (sums in fp64: the table is built once per model).
+template <class T>
+__global__ __launch_bounds__(64) void lnlinear_prepare_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              T* __restrict__ Wg, float* __restrict__ aux, int K) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  double sw = 0.0, sb = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(size_t)n * K + k];
+    const T wg = from_f32<T>(w * gamma[k]);
+    Wg[(size_t)n * K + k] = wg;
+    sw += (double)to_f32<T>(wg);
+    sb += (double)w * (double)beta[k];
+  }
+  sw = wave_sum(sw);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    aux[2 * n] = (float)(-sw);
+    aux[2 * n + 1] = (float)((double)bias[n] + sb);
+  }
 }
 
+template <class T, int KS, int RT, int NW, int LNM>
+static void launch_linear_kres(const void* A, float* X, const void* R, long r_ld, long r_plane, float eps, const void* W,
+                               const void* bias, const float* aux, void* C, int M, int N, int gelu, int planar, hipStream_t s) {
+  const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
+  if (gelu)
+    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+                       (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
+  else
+    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+                       (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
+}
+
+// A != null: plain Linear.  A == null: LayerNorm prologue on X (res may be null).
 template <int KS, int RT, int NW>
-static int linear_kres(const char* name, const void* A, const void* W, const void* bias, void* C, int M, int N,
-                       int gelu, int out_layout, int dtype, void* stream) {
+static int linear_kres(const char* name, const void* A, float* X, const void* res, int res_layout, float eps, const void* W,
+                       const void* bias, const float* aux, void* C, int M, int N, int gelu, int out_layout, int dtype,
+                       void* stream) {
   typedef LinCfg<KS, RT, NW> Cfg;
-  DSS_REQUIRE(A && W && bias && C, "%s: null pointer", name);
+  DSS_REQUIRE((A ? bias != nullptr : (X && aux)) && W && C, "%s: null pointer", name);
   DSS_REQUIRE(M > 0 && N > 0 && N % (2 * LBN) == 0 && N <= Cfg::MAXN, "%s: need M > 0, N %% %d == 0, N <= %d (M=%d N=%d)",
               name, 2 * LBN, Cfg::MAXN, M, N);
   DSS_REQUIRE(out_layout == DSS_ROW_MAJOR || out_layout == DSS_PLANAR64,
               "%s: out_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", name, out_layout);
+  DSS_REQUIRE(A || res_layout == DSS_ROW_MAJOR || res_layout == DSS_PLANAR64,
+              "%s: res_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", name, res_layout);
+  DSS_REQUIRE(A || (eps >= 0.f && (const void*)X != res && (const void*)X != C && res != C), "%s: eps < 0 or aliased buffers", name);
   hipStream_t s = (hipStream_t)stream;
   const int planar = out_layout == DSS_PLANAR64;
+  const long r_ld = res_layout == DSS_PLANAR64 ? 64 : Cfg::K, r_plane = res_layout == DSS_PLANAR64 ? 64L * M : 64;
+#define DSS_LAUNCH_KRES(TT)                                                                                              \
+  do {                                                                                                                   \
+    if (A) launch_linear_kres<TT, KS, RT, NW, 0>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu, planar, s); \
+    else if (!res) launch_linear_kres<TT, KS, RT, NW, 1>(nullptr, X, nullptr, 0, 0, eps, W, nullptr, aux, C, M, N, gelu, planar, s); \
+    else launch_linear_kres<TT, KS, RT, NW, 2>(nullptr, X, res, r_ld, r_plane, eps, W, nullptr, aux, C, M, N, gelu, planar, s); \
+  } while (0)
   switch (dtype) {
-    case DSS_F16: launch_linear_kres<f16, KS, RT, NW>(A, W, bias, C, M, N, gelu, planar, s); break;
-    case DSS_BF16: launch_linear_kres<bf16, KS, RT, NW>(A, W, bias, C, M, N, gelu, planar, s); break;
+    case DSS_F16: DSS_LAUNCH_KRES(f16); break;
+#ifndef DSS_LIN_LAB_MIN   // lab builds (quick compiles): f16 only
+    case DSS_BF16: DSS_LAUNCH_KRES(bf16); break;
+#endif
     default: return fail(DSS_ERR_BAD_ARG, "%s: dtype must be DSS_F16 or DSS_BF16 (got %d)", name, dtype);
   }
+#undef DSS_LAUNCH_KRES
   DSS_CHECK_LAUNCH(name);
   return DSS_OK;
 }
@@ -348,10 +603,47 @@ static int linear_kres(const char* name, const void* A, const void* W, const voi
 
 extern "C" int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
-  return dss::linear_kres<24, 2, 4>("dss_linear_k384", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
+  DSS_REQUIRE(A, "dss_linear_k384: null pointer");
+  return dss::linear_kres<24, 2, 4>("dss_linear_k384", A, nullptr, nullptr, 0, 0.f, W, bias, nullptr, C, M, N, gelu, out_layout, dtype, stream);
 }
 
+#ifndef DSS_LIN_LAB_MIN
 extern "C" int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
-  return dss::linear_kres<48, 1, 8>("dss_linear_k768", A, W, bias, C, M, N, gelu, out_layout, dtype, stream);
+  DSS_REQUIRE(A, "dss_linear_k768: null pointer");
+  return dss::linear_kres<48, 1, 8>("dss_linear_k768", A, nullptr, nullptr, 0, 0.f, W, bias, nullptr, C, M, N, gelu, out_layout, dtype, stream);
 }
+
+#endif
+
+extern "C" int dss_lnlinear_prepare(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg, float* aux,
+                                    int N, int K, int dtype, void* stream) {
+  DSS_REQUIRE(W && bias && gamma && beta && Wg && aux, "dss_lnlinear_prepare: null pointer");
+  DSS_REQUIRE(N > 0 && K > 0, "dss_lnlinear_prepare: need N > 0, K > 0 (N=%d K=%d)", N, K);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case DSS_F16:
+      hipLaunchKernelGGL((dss::lnlinear_prepare_kernel<dss::f16>), dim3(N), dim3(64), 0, s, W, bias, gamma, beta, (dss::f16*)Wg, aux, K);
+      break;
+    case DSS_BF16:
+      hipLaunchKernelGGL((dss::lnlinear_prepare_kernel<dss::bf16>), dim3(N), dim3(64), 0, s, W, bias, gamma, beta, (dss::bf16*)Wg, aux, K);
+      break;
+    default: return dss::fail(DSS_ERR_BAD_ARG, "dss_lnlinear_prepare: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
+  }
+  DSS_CHECK_LAUNCH("dss_lnlinear_prepare");
+  return DSS_OK;
+}
+
+extern "C" int dss_lnlinear_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                                 void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
+  DSS_REQUIRE(x, "dss_lnlinear_k384: null pointer");
+  return dss::linear_kres<24, 2, 4>("dss_lnlinear_k384", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
+}
+
+#ifndef DSS_LIN_LAB_MIN
+extern "C" int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                                 void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
+  DSS_REQUIRE(x, "dss_lnlinear_k768: null pointer");
+  return dss::linear_kres<48, 1, 8>("dss_lnlinear_k768", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
+}
+#endif

@@ -32,6 +32,12 @@ SYMBOLS = {
     "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_lnlinear_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_void_p]),
+    "dss_lnlinear_k384": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
+    "dss_lnlinear_k768": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -70,6 +76,9 @@ TIMERS: Optional[dict] = None
 
 
 class _timed:
+    """``with _timed(name, **meta):`` - HIP events around the enclosed launches when ``TIMERS`` is a dict (also used by
+    ``vit.py`` for the library GEMMs, so that bench.py can say where the time outside the HIP kernels goes)."""
+
     def __init__(self, name: str, **meta):
         self.name, self.meta = name, meta
 
@@ -210,7 +219,7 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, out: Optional[torch.T
     return out
 
 
-LINEAR_KRES_WIDTHS = {384: ("dss_linear_k384", 512), 768: ("dss_linear_k768", 256)}   # K -> (entry point, rows / workgroup)
+LINEAR_KRES_WIDTHS = {384: ("dss_linear_k384", 512), 768: ("dss_linear_k768", 256)}   # K -> (entry point, token rows per CU: 2 x 256 / 1 x 256)
 
 
 def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
@@ -230,6 +239,46 @@ def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu:
         _check(getattr(load_library(), entry)(_dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias"), _dev(out, "out"),
                                               m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
                                               _stream()), entry)
+    return out
+
+
+def lnlinear_prepare(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                     dtype: torch.dtype):
+    """Fold a LayerNorm's affine into the Linear that follows it (``dss_lnlinear_prepare``, once per layer): f32
+    ``weight [N, K]``, ``bias [N]``, ``gamma / beta [K]`` -> ``(Wg [N, K] in dtype, aux f32 [N, 2])`` for ``lnlinear``."""
+    n, k = weight.shape
+    for t in (weight, bias, gamma, beta):
+        assert t.dtype == torch.float32
+    wg = torch.empty((n, k), dtype=dtype, device=weight.device)
+    aux = torch.empty((n, 2), dtype=torch.float32, device=weight.device)
+    _check(load_library().dss_lnlinear_prepare(_dev(weight, "weight"), _dev(bias, "bias"), _dev(gamma, "gamma"),
+                                               _dev(beta, "beta"), _dev(wg, "Wg"), _dev(aux, "aux"), n, k, dtype_code(dtype),
+                                               _stream()), "dss_lnlinear_prepare")
+    return wg, aux
+
+
+def lnlinear(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor, aux: torch.Tensor, eps: float,
+             gelu: bool = False, planar: bool = False, residual_planar: bool = False) -> torch.Tensor:
+    """``act(LN(x (+= residual)) @ W^T + b)`` in one kernel (``dss_lnlinear_k384 / _k768``): ``x`` f32 ``[..., K]`` is the
+    residual stream and is UPDATED IN PLACE when ``residual`` is given (``[..., K]``, or ``[K/64, rows, 64]`` with
+    ``residual_planar``); ``wg, aux`` from ``lnlinear_prepare``.  Returns ``[..., N]`` (or ``[N/64, rows, 64]``)."""
+    assert x.dtype == torch.float32 and aux.dtype == torch.float32
+    k = x.shape[-1]
+    if k not in LINEAR_KRES_WIDTHS:
+        raise ValueError(f"lnlinear: reduction dimension must be one of {sorted(LINEAR_KRES_WIDTHS)} (got {k})")
+    n = wg.shape[0]
+    m = x.numel() // k
+    assert wg.shape[1] == k and tuple(aux.shape) == (n, 2)
+    if residual is not None:
+        assert residual.dtype == wg.dtype and tuple(residual.shape) == ((k // 64, m, 64) if residual_planar else tuple(x.shape))
+    entry = LINEAR_KRES_WIDTHS[k][0].replace("dss_linear", "dss_lnlinear")
+    shape = (n // 64, m, 64) if planar else (*x.shape[:-1], n)
+    out = torch.empty(shape, dtype=wg.dtype, device=x.device)
+    with _timed("lnlinear", m=m, n=n, k=k, gelu=gelu, res=residual is not None):
+        _check(getattr(load_library(), entry)(_dev(x, "x"), 0 if residual is None else _dev(residual, "residual"),
+                                              PLANAR64 if residual_planar else ROW_MAJOR, float(eps), _dev(wg, "Wg"),
+                                              _dev(aux, "aux"), _dev(out, "out"), m, n, int(gelu),
+                                              PLANAR64 if planar else ROW_MAJOR, dtype_code(wg.dtype), _stream()), entry)
     return out
 
 

@@ -20,8 +20,6 @@ loads unchanged.
 """
 from __future__ import annotations
 
-import os
-
 import math
 from pathlib import Path
 from typing import Dict, Optional, Tuple
@@ -88,7 +86,8 @@ class DinoViT:
     """Inference-only DINO ViT holding its weights on one GPU."""
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
-                 dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf"):
+                 dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
+                 linear_kres: int = 2, fuse_ln: bool = True):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -104,11 +103,15 @@ class DinoViT:
         # the TANH approximation (measured: 3.6e-7 from tanh-GELU, 4.7e-4 from erf-GELU).  It is NOT DINO's function:
         # opt-in only, never used for the reported numbers.
         self.gelu = gelu
-        # qkv / attn.proj of the D = 384 / 768 models on the K-resident kernel (dss_linear_k384/_k768), planar outputs that
-        # the attention and LayerNorm kernels read in place; DSS_LINEAR_K384=0 keeps the library GEMMs (A/B switch)
-        # (DSS_LINEAR_K384=1: qkv + proj of the D = 384 models only; 2, the default: also fc1 with the erf-GELU fused into
-        #  its epilogue, for D = 384 and D = 768)
-        self.linear_k384 = int(os.environ.get("DSS_LINEAR_K384", "2") or 0)
+        # linear_kres: which Linear layers run on the K-resident kernel (dss_linear_k384 / _k768, planar outputs that the
+        # attention and LayerNorm kernels read in place).  0: none (library GEMMs: the A/B arm); 1: qkv + proj of the D = 384
+        # models; 2 (default): also fc1 with the erf-GELU fused into its epilogue, for D = 384 and D = 768.
+        # fuse_ln (default): the residual add + LayerNorm in front of those Linear layers is their A prologue
+        # (dss_lnlinear_*: norm1 -> qkv at D = 384, norm2 -> fc1+GELU at D = 384 / 768) instead of a pass of its own.
+        if linear_kres not in (0, 1, 2):
+            raise ValueError("linear_kres must be 0, 1 or 2")
+        self.linear_k384 = int(linear_kres)
+        self.fuse_ln = bool(fuse_ln)
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -144,13 +147,22 @@ class DinoViT:
                 fc1_w=lp(sd[p + "mlp.fc1.weight"]), fc1_b=lp(sd[p + "mlp.fc1.bias"]),
                 fc2_w=lp(sd[p + "mlp.fc2.weight"]), fc2_b=lp(sd[p + "mlp.fc2.bias"]),
             ))
+        hip.load_library()  # fail now, not mid-run, if the kernels are missing
+        if self.fuse_ln and self.linear_k384 and d in hip.LINEAR_KRES_WIDTHS:
+            for i, blk in enumerate(self.blocks):   # LayerNorm affine folded into the Linear behind it, once per layer
+                p = f"blocks.{i}."
+                if d == 384:
+                    blk["qkv_wg"], blk["qkv_aux"] = hip.lnlinear_prepare(f32(sd[p + "attn.qkv.weight"]), f32(sd[p + "attn.qkv.bias"]),
+                                                                         blk["n1w"], blk["n1b"], dtype)
+                if self.linear_k384 >= 2 and self.gelu == "erf":
+                    blk["fc1_wg"], blk["fc1_aux"] = hip.lnlinear_prepare(f32(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"]),
+                                                                         blk["n2w"], blk["n2b"], dtype)
         # final LayerNorm: only the CLS-token path (`forward_cls`, extract_bbox_features) needs it
         self.norm_w = f32(sd["norm.weight"]) if "norm.weight" in sd else None
         self.norm_b = f32(sd["norm.bias"]) if "norm.bias" in sd else None
         self.scale = 64 ** -0.5
         assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
         self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
-        hip.load_library()  # fail now, not mid-run, if the kernels are missing
         setup_gemm_tuning()
 
     # ------------------------------------------------------------------------------------------
@@ -173,7 +185,8 @@ class DinoViT:
         hp, wp = h // p, w // p
         t = hp * wp + 1
         patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
-        tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
+        with hip._timed("library_gemm", m=b * hp * wp, n=d, k=patches.shape[-1], what="patch_embed"):
+            tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
         cls_row, pos = self._pos(hp * p, wp * p)
         x = torch.empty((b, t, d), dtype=torch.float32, device=self.device)  # fp32 residual stream
         x[:, 0] = cls_row
@@ -189,26 +202,32 @@ class DinoViT:
         kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
         for i in range(nblocks):
             blk = self.blocks[i]
-            hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
+            if k384 and "qkv_wg" in blk:      # x += pending; LN1; qkv - one kernel
+                qkv = hip.lnlinear(x, pending, blk["qkv_wg"], blk["qkv_aux"], LN_EPS, planar=True)   # [3h, B*T, 64]
+            else:
+                hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
+                qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True) if k384 else \
+                    F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
             if k384:
-                qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)       # [3h, B*T, 64]
                 o = hip.attention(qkv, heads, self.scale, planar_bt=(b, t))
                 pending = hip.linear_kres(o, blk["proj_w"], blk["proj_b"], planar=True)    # [D/64, B*T, 64]
-                hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
-                                     residual_planar=True)
             else:
-                qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
                 o = hip.attention(qkv, heads, self.scale)
                 pending = F.linear(o, blk["proj_w"], blk["proj_b"])
-                hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending)
-            if kres_fc1:
-                f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)        # row-major: fc2 is a library GEMM
-            elif self.gelu == "erf":
-                f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
+            if kres_fc1 and "fc1_wg" in blk:   # x += pending; LN2; fc1; GELU - one kernel (row-major out: fc2 is a library GEMM)
+                f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=True, residual_planar=bool(k384))
             else:
-                f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),
-                                             use_gelu=True).view(b, t, -1)
-            pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
+                hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
+                                     residual_planar=bool(k384))
+                if kres_fc1:
+                    f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)
+                elif self.gelu == "erf":
+                    f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
+                else:
+                    f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),
+                                                 use_gelu=True).view(b, t, -1)
+            with hip._timed("library_gemm", m=b * t, n=d, k=f1.shape[-1], what="fc2"):
+                pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
         return x, pending
 
     @torch.no_grad()
@@ -255,7 +274,8 @@ class DinoViT:
             k = F.linear(h32, blk["k_w32"], blk["k_b32"])
         else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
             hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
-            k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
+            with hip._timed("library_gemm", m=b * t, n=d, k=d, what="k_proj"):
+                k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
             if _finalize and n > 0:
                 return hip.kfeatures_finalize(k, blk["k_b32"])
             k += blk["k_b32"]

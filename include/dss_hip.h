@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DSS_ABI_VERSION 3
+#define DSS_ABI_VERSION 4
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -91,6 +91,24 @@ int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int
                     int dtype, void* stream);
 int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
                     int dtype, void* stream);
+
+/* ---- a6 + a6': residual add + LayerNorm + Linear in ONE kernel (DINO Block: `x = x + branch; h = norm(x); y = lin(h)`,
+ * i.e. norm1 -> attn.qkv and norm2 -> mlp.fc1 (+ GELU); SURVEY.md Appendix A, reached from extract/extract.py:94).
+ *   x        [M, K] f32, the residual stream, UPDATED IN PLACE: x += residual (skipped when residual == NULL);
+ *   residual [M, K] in `dtype`, layout res_layout (DSS_ROW_MAJOR or DSS_PLANAR64), or NULL;
+ *   C        = act( LayerNorm_eps(x) . W^T + bias ) with LayerNorm's gamma/beta, W and bias given in the folded form that
+ *              dss_lnlinear_prepare builds once per layer:  Wg[n][k] = dtype(W[n][k] gamma[k]),
+ *              aux[n] = (-sum_k Wg[n][k],  bias[n] + sum_k W[n][k] beta[k])  (f32 [N, 2]).
+ * The kernel keeps f16(x) as its K-resident operand (ONE rounding, of x itself) and applies mean / sigma exactly:
+ * C = rstd * (x16 . Wg^T - mean * sum_k Wg + sigma * b'), the two corrections as one fp32 MFMA step.  Statistics in fp32
+ * from pivot-shifted moments (biased variance, like torch.nn.LayerNorm).  Same shapes / layouts / dtypes as dss_linear_k384
+ * / _k768 (K = 384 / 768).  x, residual and C must not alias. */
+int dss_lnlinear_prepare(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg, float* aux,
+                         int N, int K, int dtype, void* stream);
+int dss_lnlinear_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux, void* C,
+                      int M, int N, int gelu, int out_layout, int dtype, void* stream);
+int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux, void* C,
+                      int M, int N, int gelu, int out_layout, int dtype, void* stream);
 
 /* ---- a10: row L2 normalisation -------------------------------------------------------------
  * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */

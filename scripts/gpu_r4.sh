@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-4 GPU session script (run through gpurun): stages given as arguments; logs -> gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+REPO_DIR=$PWD
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
+bench_summary() { python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print({k: d.get(k) for k in ('value', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_in_loop_ms_per_step')})
+for k, v in d['kernels'].items(): print(k, v.get('launches'), v.get('avg_ms'), v.get('frac'), v.get('passes_per_image', ''))
+"; }
+for STAGE in "$@"; do
+  echo "=== $STAGE"
+  case $STAGE in
+    ln_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -rf --tb=short -k "lnlinear or linear_kres or layernorm" 2>&1 | tail -30 > gpurun_out/pytest_ln.log; tail -15 gpurun_out/pytest_ln.log;;
+    vit_tests) timeout 1200 python -m pytest tests/test_gpu_e2e.py -m gpu -q --timeout 900 -rf --tb=short -k "vit or indexing or fp16_path or end_to_end_eigenvectors" 2>&1 | tail -30 > gpurun_out/pytest_vit.log; tail -15 gpurun_out/pytest_vit.log;;
+    ln_ab) timeout 300 python scripts/debug/lnlinear_ab.py > gpurun_out/lnlinear_ab.log 2>&1; VIT_BATCH=580 timeout 300 python scripts/debug/lnlinear_ab.py >> gpurun_out/lnlinear_ab.log 2>&1; K=768 timeout 300 python scripts/debug/lnlinear_ab.py >> gpurun_out/lnlinear_ab.log 2>&1; cat gpurun_out/lnlinear_ab.log;;
+    tests) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -x 2>&1 | tail -80 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
+    tests_all) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -4 gpurun_out/smoke.log;;
+    bench_quick) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS:-} 2> gpurun_out/bench_quick.err | tee gpurun_out/bench_quick.json | bench_summary; tail -2 gpurun_out/bench_quick.err;;
+    bench_quick2) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS2:-} 2> gpurun_out/bench_quick2.err | tee gpurun_out/bench_quick2.json | bench_summary; tail -2 gpurun_out/bench_quick2.err;;
+    bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
+    bench_c3) timeout 900 python bench.py --model dino_vitb8 --K 15 --batch 512 --vit-batch 16 --cpu-images 2 --parity-images 2 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; echo "bench_c3 exit: $?"; tail -2 gpurun_out/bench_c3.err; cut -c1-600 gpurun_out/bench_c3.json;;
+    prof)   # per-kernel time of the bench command (rocprofv3 kernel trace + stats); PROF_TAG names the output
+      T=${PROF_TAG:-c2}; rm -rf gpurun_out/prof_$T && mkdir -p gpurun_out/prof_$T
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO_DIR/gpurun_out/prof_$T -o bench -- python $REPO_DIR/bench.py --steps 2 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 --dino-like-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/prof_$T/bench.json 2> $REPO_DIR/gpurun_out/prof_$T/bench.err)
+      echo "prof exit: $?"; python scripts/rocpd_summary.py gpurun_out/prof_$T/bench_results.db > gpurun_out/kernel_stats_$T.csv; head -16 gpurun_out/kernel_stats_$T.csv | cut -c1-200
+      rm -rf gpurun_out/prof_$T;;
+    pmc)    # hardware counters, ONE rocprofv3 pass per group (--kernel-trace only); PMC_GROUPS restricts, PROF_TAG names
+      T=${PROF_TAG:-c2}
+      declare -A PMCG=( [mfma]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+                          [wait]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES"
+                          [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" )
+      for G in ${PMC_GROUPS:-mfma wait fetch write}; do
+        rm -rf gpurun_out/pmcrun_$G && mkdir -p gpurun_out/pmcrun_$G
+        (cd /tmp && timeout 600 rocprofv3 --pmc ${PMCG[$G]} --kernel-trace -d $REPO_DIR/gpurun_out/pmcrun_$G -o pmc -- python $REPO_DIR/bench.py --steps 1 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 --dino-like-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/pmc_${T}_$G.bench.json 2> $REPO_DIR/gpurun_out/pmcrun_$G/bench.err)
+        echo "pmc $G exit: $?"
+        python scripts/rocpd_pmc_multi.py gpurun_out/pmcrun_$G/pmc_results.db 2 > gpurun_out/pmc_${T}_$G.csv; head -6 gpurun_out/pmc_${T}_$G.csv | cut -c1-220
+        rm -rf gpurun_out/pmcrun_$G
+      done;;
+    *) echo "unknown stage $STAGE";;
+  esac
+done

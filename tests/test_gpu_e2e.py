@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _models(name, seed, jitter, dtype):
+def _models(name, seed, jitter, dtype, **vit_kwargs):
     sd = synthetic.synthetic_state_dict(name, seed, jitter)
-    return DinoViT(name, sd, DEV, dtype), vit_ref.build_ref_vit(name, sd)
+    return DinoViT(name, sd, DEV, dtype, **vit_kwargs), vit_ref.build_ref_vit(name, sd)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
@@ -109,16 +109,16 @@ def test_patch_indexing_exact_probe_on_the_hip_path(golden_dir):
     assert (tok_golden == tok_golden[:, :1]).all() and (tok_ours == tok_ours[:, :1]).all()
 
 
-@pytest.mark.parametrize("env", [{"DSS_LINEAR_K384": "0"}, {"DSS_LINEAR_K384": "1"}, {"DSS_LINEAR_K384": "0", "model": "dino_vitb16"},
-                                 {"DSS_LINEAR_K384": "2", "model": "dino_vitb16"}])
-def test_vit_opt_in_kernel_paths_match_oracle(env, monkeypatch):
-    """The ways through the ViT's Linear layers (library GEMMs only; K-resident qkv/proj only; ViT-B with and without
-    the fused fc1+GELU kernel at K = 768) against the fp32 oracle ViT, same bar as the default path."""
-    env = dict(env)
-    name = env.pop("model", "dino_vits16")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    model, ref = _models(name, 7, 0.05, torch.float16)
+@pytest.mark.parametrize("cfg", [{"linear_kres": 0}, {"linear_kres": 1}, {"linear_kres": 1, "fuse_ln": False},
+                                 {"linear_kres": 2, "fuse_ln": False}, {"linear_kres": 0, "model": "dino_vitb16"},
+                                 {"linear_kres": 2, "model": "dino_vitb16"}, {"linear_kres": 2, "fuse_ln": False, "model": "dino_vitb16"}])
+def test_vit_opt_in_kernel_paths_match_oracle(cfg):
+    """The ways through the ViT's Linear layers (library GEMMs only; K-resident qkv/proj only; with and without the LayerNorm
+    fused into the K-resident kernels' prologue; ViT-B with and without the fused fc1+GELU kernel at K = 768) against the fp32
+    oracle ViT, same bar as the default path."""
+    cfg = dict(cfg)
+    name = cfg.pop("model", "dino_vits16")
+    model, ref = _models(name, 7, 0.05, torch.float16, **cfg)
     imgs = np.stack([synthetic.synthetic_image(20 + i, 100, 130) for i in range(2)])
     k = model.extract_k(torch.from_numpy(imgs).to(DEV)).cpu()
     for i in range(2):

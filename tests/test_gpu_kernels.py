@@ -155,6 +155,103 @@ def test_linear_kres_rejects_bad_shapes():
                         torch.zeros(64, dtype=torch.float16, device=DEV))
 
 
+# ----------------------------------------------------------------------------- residual add + LayerNorm + Linear in one kernel
+def _lnlinear_case(m, n, k, dtype, seed, offset=0.5, outliers=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, k, generator=g) * 3 + offset
+    if outliers:                     # what trained DINO residual streams look like: a few channels carry 150-300
+        x[:, 7] += 250.0
+        x[:, 100] -= 180.0
+        x[:, k - 3] += 300.0
+    r = (torch.randn(m, k, generator=g) * 2).to(dtype)
+    w = torch.randn(n, k, generator=g) * 0.05 * (384 / k) ** 0.5
+    b = torch.randn(n, generator=g) * 0.2
+    gamma, beta = torch.randn(k, generator=g) * 0.5 + 1.0, torch.randn(k, generator=g) * 0.3
+    return x, r, w, b, gamma, beta
+
+
+@pytest.mark.parametrize("m,n,k", [(901, 1152, 384), (512, 1536, 384), (1, 64, 384), (77, 384, 384), (1025, 128, 384),
+                                   (2 * 901 + 5, 1536, 384), (3601, 3072, 768), (256, 768, 768), (1, 64, 768), (513, 128, 768)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("res", [None, "rows", "planar"])
+def test_lnlinear_matches_fp64_reference(m, n, k, dtype, gelu, res):
+    """dss_lnlinear_k384/_k768 against the fp64 composition x += r; LayerNorm(x); Linear; (erf GELU) it replaces.  The
+    residual stream must come back as the SAME fp32 sum the standalone LayerNorm pass writes (bit-exact); the output bar is
+    the half dtype's output rounding plus the operand rounding of x (|x| <= ~15 sigma here), as for the plain kernel."""
+    x, r, w, b, gamma, beta = _lnlinear_case(m, n, k, dtype, m + n + k + 11)
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), dtype)
+    xd = x.to(DEV)
+    rd = None if res is None else (_to_planar(r) if res == "planar" else r).to(DEV)
+    out = hip.lnlinear(xd, rd, wg, aux, 1e-6, gelu=gelu, planar=(res == "planar"), residual_planar=(res == "planar"))
+    out = (hip.planar_to_rows(out) if res == "planar" else out).float().cpu()
+    xsum = x if res is None else x + r.float()
+    assert torch.equal(xd.cpu(), xsum)
+    ref = F.linear(F.layer_norm(xsum.double(), (k,), gamma.double(), beta.double(), 1e-6), w.double(), b.double())
+    if gelu:
+        ref = F.gelu(ref)
+    assert out.shape == (m, n)
+    tol = (1.5e-3 if dtype == torch.float16 else 1.2e-2) * max(1.0, ref.abs().max().item())
+    assert (out.double() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("k,n", [(384, 1152), (768, 3072)])
+def test_lnlinear_outlier_channels_and_large_mean(k, n):
+    """Rows whose mean is far from zero and whose variance is carried by three outlier channels (the statistics are pivot-
+    shifted moments, the mean / sigma corrections exact fp32 products): still within the f16 operand rounding of the
+    LayerNorm -> Linear pair it replaces (compared with that pair: same weights, standalone dss_layernorm_fwd + dss_linear)."""
+    m = 700
+    for offset, outliers in ((40.0, False), (0.0, True), (-25.0, True)):
+        x, r, w, b, gamma, beta = _lnlinear_case(m, n, k, torch.float16, 99, offset=offset, outliers=outliers)
+        wg, aux = hip.lnlinear_prepare(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), torch.float16)
+        xa, xb = x.to(DEV), x.to(DEV)
+        out = hip.lnlinear(xa, r.to(DEV), wg, aux, 1e-6).float().cpu()
+        h = hip.layernorm(xb, gamma.to(DEV), beta.to(DEV), 1e-6, torch.float16, residual=r.to(DEV))
+        two = hip.linear_kres(h, w.half().to(DEV), b.half().to(DEV)).float().cpu()
+        assert torch.equal(xa, xb)
+        ref = F.linear(F.layer_norm((x + r.float()).double(), (k,), gamma.double(), beta.double(), 1e-6), w.double(), b.double())
+        e_fused, e_two = (out.double() - ref).abs().max().item(), (two.double() - ref).abs().max().item()
+        assert e_fused <= max(2.5 * e_two, 2e-3 * ref.abs().max().item()), (offset, outliers, e_fused, e_two)
+
+
+@pytest.mark.parametrize("k", [384, 768])
+def test_lnlinear_ragged_block_touches_nothing_outside(k):
+    """M not a multiple of the 64-row wave tile or of the workgroup: rows past M of x, the residual and the output (all three
+    embedded in larger guard buffers) stay untouched, rows below M are all written."""
+    m, n = 515, 128
+    g = torch.Generator().manual_seed(4)
+    xbig = torch.full((m + 64, k), 3.0, device=DEV)
+    xbig[:m] = torch.randn(m, k, generator=g).to(DEV)
+    x0 = xbig.clone()
+    r = torch.randn(m, k, generator=g).half().to(DEV)
+    w, b = torch.randn(n, k, generator=g) * 0.05, torch.zeros(n)
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), b.to(DEV), torch.ones(k, device=DEV), torch.zeros(k, device=DEV), torch.float16)
+    lib = hip.load_library()
+    entry = hip.LINEAR_KRES_WIDTHS[k][0].replace("dss_linear", "dss_lnlinear")
+    for planar in (False, True):
+        xbig.copy_(x0)
+        big = torch.full((m * n + 4096,), 7.0, dtype=torch.float16, device=DEV)
+        rc = getattr(lib, entry)(xbig.data_ptr(), r.data_ptr(), hip.ROW_MAJOR, 1e-6, wg.data_ptr(), aux.data_ptr(), big.data_ptr(), m, n,
+                                 0, hip.PLANAR64 if planar else hip.ROW_MAJOR, hip.dtype_code(torch.float16),
+                                 torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.all(big[m * n:] == 7.0) and not torch.any(big[: m * n] == 7.0)
+        assert torch.equal(xbig[m:], x0[m:]) and torch.equal(xbig[:m], x0[:m] + r.float())
+
+
+def test_lnlinear_rejects_bad_arguments():
+    x = torch.zeros(8, 384, device=DEV)
+    wg, aux = torch.zeros(64, 384, dtype=torch.float16, device=DEV), torch.zeros(64, 2, device=DEV)
+    lib = hip.load_library()
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros(8, 64, dtype=torch.float16, device=DEV)
+    assert lib.dss_lnlinear_k384(x.data_ptr(), 0, 0, 1e-6, wg.data_ptr(), 0, out.data_ptr(), 8, 64, 0, 0, 1, s) == -1   # no aux
+    assert lib.dss_lnlinear_k384(x.data_ptr(), 0, 7, 1e-6, wg.data_ptr(), aux.data_ptr(), out.data_ptr(), 8, 64, 0, 0, 1, s) == -1
+    assert lib.dss_lnlinear_k384(0, 0, 0, 1e-6, wg.data_ptr(), aux.data_ptr(), out.data_ptr(), 8, 64, 0, 0, 1, s) == -1
+    assert lib.dss_lnlinear_k384(x.data_ptr(), 0, 0, 1e-6, wg.data_ptr(), aux.data_ptr(), out.data_ptr(), 8, 64, 0, 0, 1, s) == 0
+
+
 # ----------------------------------------------------------------------------- attention
 def _attention_ref(qkv, heads, scale):
     b, t, _ = qkv.shape
