@@ -1,6 +1,9 @@
 """Probe: can the library fc2 GEMM accumulate straight into the fp32 residual stream (x += h1 . W2^T, f16 operands, f32 C = D,
 beta = 1: torch.addmm(..., out_dtype=float32, out=x)) at a cost below the residual prologue it would remove (~115 us)?
-The fc2 bias rides on an extra K column (K = 1536 + 64, column 1536 of h1 constant)."""
+The fc2 bias rides on an extra K column (K = 1536 + 64, column 1536 of h1 constant).
+Result (round 4, gpurun_out -> DESIGN.md §6): the accumulate-GEMM costs +50 us (hipBLASLt's heuristic solution; TunableOp does
+not cover addmm with out_dtype), the prologue it frees saves 54 us: built into DinoViT, measured equal end to end (168.6 vs
+167.7 ms per step on the same box), removed again."""
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dss_amd
