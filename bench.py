@@ -88,8 +88,6 @@ def parse():
                          "the first GPU process on a fresh box runs ~20 %% slower until clocks/power have ramped")
     ap.add_argument("--linear-kres", type=int, default=2, choices=[0, 1, 2],
                     help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
-    ap.add_argument("--no-fc2-accumulate", action="store_true",
-                    help="A/B arm: fc2 writes an f16 branch output (added by the next block's prologue) instead of x += ...")
     ap.add_argument("--no-fuse-ln", action="store_true",
                     help="A/B arm: standalone residual + LayerNorm passes instead of the fused dss_lnlinear_* prologue")
     ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
@@ -476,8 +474,7 @@ def main():
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
-    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
-                    fc2_accumulate=not a.no_fc2_accumulate)
+    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -620,7 +617,7 @@ def main():
             # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
             "layernorm_launches_per_forward": round(kern.get("layernorm", {}).get("launches", 0) / max(n_forwards, 1), 2),
             "library_gemm_ms_per_step": round(kern.get("library_gemm", {}).get("total_ms", 0.0) / steps_out, 3),
-            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fc2_accumulate": not a.no_fc2_accumulate},
+            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln},
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
             "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
@@ -639,7 +636,7 @@ def main():
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
-                     fuse_ln=not a.no_fuse_ln, fc2_accumulate=not a.no_fc2_accumulate)
+                     fuse_ln=not a.no_fuse_ln)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

@@ -87,7 +87,7 @@ class DinoViT:
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
-                 linear_kres: int = 2, fuse_ln: bool = True, fc2_accumulate: bool = True):
+                 linear_kres: int = 2, fuse_ln: bool = True):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -112,11 +112,6 @@ class DinoViT:
             raise ValueError("linear_kres must be 0, 1 or 2")
         self.linear_k384 = int(linear_kres)
         self.fuse_ln = bool(fuse_ln)
-        # fc2_accumulate (default; D = 384 with the fused norm2 -> fc1+GELU kernel): the library fc2 GEMM accumulates straight
-        # into the fp32 residual stream (x += h . W2^T: f16 operands, fp32 C = D, beta = 1) instead of writing an f16 branch
-        # output that the next block's prologue has to read, add and write back; its bias rides on one of 64 extra hidden
-        # columns that fc1 produces as the constant 1 (`_pad_mlp_for_accumulate`)
-        self.fc2_accumulate = bool(fc2_accumulate)
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -162,8 +157,6 @@ class DinoViT:
                 if self.linear_k384 >= 2 and self.gelu == "erf":
                     blk["fc1_wg"], blk["fc1_aux"] = hip.lnlinear_prepare(f32(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"]),
                                                                          blk["n2w"], blk["n2b"], dtype)
-                    if self.fc2_accumulate and d == 384:
-                        self._pad_mlp_for_accumulate(blk)
         # final LayerNorm: only the CLS-token path (`forward_cls`, extract_bbox_features) needs it
         self.norm_w = f32(sd["norm.weight"]) if "norm.weight" in sd else None
         self.norm_b = f32(sd["norm.bias"]) if "norm.bias" in sd else None
@@ -173,25 +166,6 @@ class DinoViT:
         setup_gemm_tuning()
 
     # ------------------------------------------------------------------------------------------
-    GELU_ONE = 1.1444507183528787     # GELU_erf(v) = 1: a hidden column with W = 0 and this bias is the constant 1 (exactly,
-                                      # after the f16 rounding of the output: the spacing around 1 is 5e-4, the kernel's error 3e-7)
-
-    def _pad_mlp_for_accumulate(self, blk: dict) -> None:
-        """64 extra hidden columns for `x += GELU(fc1(.)) . W2^T + b2` as ONE accumulate-GEMM: fc1 rows [H, H + 64) are zero
-        with bias GELU_ONE in column H (the others 0 -> GELU(0) = 0), W2 gets b2 (rounded to the operand dtype, as the
-        library's bias epilogue takes it) as column H.  `fc2_wp_t` is the [H + 64, D] view the GEMM consumes."""
-        wg, aux = blk["fc1_wg"], blk["fc1_aux"]
-        hid, k = wg.shape
-        wgp = torch.zeros((hid + 64, k), dtype=wg.dtype, device=wg.device)
-        wgp[:hid] = wg
-        auxp = torch.zeros((hid + 64, 2), dtype=torch.float32, device=aux.device)
-        auxp[:hid] = aux
-        auxp[hid, 1] = self.GELU_ONE
-        w2p = torch.zeros((blk["fc2_w"].shape[0], hid + 64), dtype=wg.dtype, device=wg.device)
-        w2p[:, :hid] = blk["fc2_w"]
-        w2p[:, hid] = blk["fc2_b"]
-        blk["fc1_wgp"], blk["fc1_auxp"], blk["fc2_wp_t"] = wgp, auxp, w2p.t()
-
     def _pos(self, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(cls_token + pos[0]) as ``[D]`` and pos[1:] as ``[N, D]`` on the device, fp32."""
         key = (h, w)
@@ -205,7 +179,7 @@ class DinoViT:
     def _run_blocks(self, img_u8: torch.Tensor, nblocks: int):
         """Transform + patch embedding + position encoding, then blocks ``0 .. nblocks-1`` in full.  Returns the fp32
         residual stream ``x [B, T, D]`` and the last branch output not yet added to it (``pending``, fused into the
-        next LayerNorm by the caller; ``None`` if ``nblocks == 0`` or if fc2 accumulated into ``x`` itself)."""
+        next LayerNorm by the caller; ``None`` if ``nblocks == 0``)."""
         b, h, w, _ = img_u8.shape
         p, d, heads = self.patch_size, self.embed_dim, self.num_heads
         hp, wp = h // p, w // p
@@ -240,13 +214,6 @@ class DinoViT:
             else:
                 o = hip.attention(qkv, heads, self.scale)
                 pending = F.linear(o, blk["proj_w"], blk["proj_b"])
-            if kres_fc1 and "fc1_wgp" in blk:  # x += pending; LN2; fc1; GELU - one kernel -; then x += f1 . W2^T + b2 in the GEMM
-                f1 = hip.lnlinear(x, pending, blk["fc1_wgp"], blk["fc1_auxp"], LN_EPS, gelu=True, residual_planar=bool(k384))
-                x2 = x.view(b * t, d)
-                with hip._timed("library_gemm", m=b * t, n=d, k=f1.shape[-1], what="fc2+=x"):
-                    torch.addmm(x2, f1.view(b * t, -1), blk["fc2_wp_t"], out_dtype=torch.float32, out=x2)
-                pending = None
-                continue
             if kres_fc1 and "fc1_wg" in blk:   # x += pending; LN2; fc1; GELU - one kernel (row-major out: fc2 is a library GEMM)
                 f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=True, residual_planar=bool(k384))
             else:
@@ -274,7 +241,7 @@ class DinoViT:
         if img_u8.shape[1] < self.patch_size or img_u8.shape[2] < self.patch_size:
             raise ValueError(f"image {tuple(img_u8.shape[1:3])} is smaller than one {self.patch_size}x{self.patch_size} patch")
         x, pending = self._run_blocks(img_u8, self.depth)
-        cls = x[:, 0] if pending is None else x[:, 0] + pending[:, 0].float()   # the Mlp branch output is row-major [B, T, D]
+        cls = x[:, 0] + pending[:, 0].float()   # the Mlp branch output is row-major [B, T, D] on every path
         return F.layer_norm(cls, (self.embed_dim,), self.norm_w, self.norm_b, LN_EPS)
 
     @torch.no_grad()

@@ -109,7 +109,7 @@ def test_patch_indexing_exact_probe_on_the_hip_path(golden_dir):
     assert (tok_golden == tok_golden[:, :1]).all() and (tok_ours == tok_ours[:, :1]).all()
 
 
-@pytest.mark.parametrize("cfg", [{"linear_kres": 0}, {"linear_kres": 1}, {"linear_kres": 1, "fuse_ln": False}, {"fc2_accumulate": False},
+@pytest.mark.parametrize("cfg", [{"linear_kres": 0}, {"linear_kres": 1}, {"linear_kres": 1, "fuse_ln": False},
                                  {"linear_kres": 2, "fuse_ln": False}, {"linear_kres": 0, "model": "dino_vitb16"},
                                  {"linear_kres": 2, "model": "dino_vitb16"}, {"linear_kres": 2, "fuse_ln": False, "model": "dino_vitb16"}])
 def test_vit_opt_in_kernel_paths_match_oracle(cfg):
