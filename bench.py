@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--min-warmup-seconds", type=float, default=4.0,
                     help="keep running untimed warm-up steps (beyond --warmup) until this much wall time has passed: "
                          "the first GPU process on a fresh box runs ~20 %% slower until clocks/power have ramped")
+    ap.add_argument("--affinity", default="fused", choices=["fused", "split", "fp32"],
+                    help="affinity build (spectral.laplacian_eigs_from_features affinity_mode); 'fused' is the pipeline's")
+    ap.add_argument("--gemm-tuning", default="table", choices=["table", "online", "off"],
+                    help="DinoViT(gemm_tuning=...): shipped TunableOp table / also tune new shapes on line / leave TunableOp alone")
     ap.add_argument("--linear-kres", type=int, default=2, choices=[0, 1, 2],
                     help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
     ap.add_argument("--no-fuse-ln", action="store_true",
@@ -139,12 +143,12 @@ _OVERLAP = {}
 _STREAMS = {}
 
 
-def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
-    """One pass of the hot path over one batch: features + eigs for every image."""
+def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16", mode="fused"):
+    """One pass of the hot path over one batch: features + eigs for every image (``mode``: the affinity build)."""
     if overlap:  # spectral stage of sub-batch i on a side stream under the ViT of sub-batch i+1
-        key = (id(model), K, vit_batch)
+        key = (id(model), K, vit_batch, mode)
         if key not in _OVERLAP:
-            _OVERLAP[key] = pipeline.OverlappedExtractor(model, K, vit_batch)
+            _OVERLAP[key] = pipeline.OverlappedExtractor(model, K, vit_batch, affinity_mode=mode)
         _, ev, vec, info = _OVERLAP[key](imgs)
         return ev, vec, info
     if nstreams > 1:  # ViT forwards of consecutive sub-batches on alternating streams (opt-in, see --vit-streams)
@@ -159,7 +163,6 @@ def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
         for st in pool:
             cur.wait_stream(st)
     else:
-        mode = os.environ.get("DSS_AFFINITY", "fused")
         if mode == "fused" and w_dtype == "u16":
             # the K projection hands over fp32 features (what extract_features would save), their f16 copy and the
             # inverse norms in one pass (hip.kfeatures_finalize); the affinity build starts from the f16 rows
@@ -170,8 +173,7 @@ def step(model, imgs, K, vit_batch, overlap=False, nstreams=1, w_dtype="u16"):
         ks = [model.extract_k(imgs[s:s + vit_batch]) for s in range(0, imgs.shape[0], vit_batch)]
     k = torch.cat(ks) if len(ks) > 1 else ks[0]
     # strict=False, retry=False: no device->host sync inside the step (convergence is checked once, after timing)
-    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype,
-                                                 affinity_mode=os.environ.get("DSS_AFFINITY", "fused"))
+    return spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype, affinity_mode=mode)
 
 
 class ImageFeeder:
@@ -250,12 +252,11 @@ def chunk_counts(cnt: int, vit_batch: int):
     return [min(vit_batch, cnt - s) for s in range(0, cnt, vit_batch)]
 
 
-def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16"):
+def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fused"):
     """One step whose images arrive through the feeder: forward j reads global chunk ``c0 + j``; before it is enqueued the
     copy of the NEXT chunk (this step's, or ``nxt`` = (chunk id, count) of the following step's first) is put on the copy
     stream.  Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
     counts = chunk_counts(cnt, vit_batch)
-    mode = os.environ.get("DSS_AFFINITY", "fused")
     f16 = mode == "fused" and w_dtype == "u16"
     parts = []
     for j, n in enumerate(counts):
@@ -275,7 +276,7 @@ def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16"):
     return (*out, len(counts))
 
 
-def summarize_timers(timers, n_patches, dim, depth_attn):
+def summarize_timers(timers, n_patches, dim, depth_attn, affinity_mode="fused"):
     """Average HIP-event duration per launch and the algorithmic work per launch."""
     out = {}
     for name, recs in timers.items():
@@ -304,7 +305,7 @@ def summarize_timers(timers, n_patches, dim, depth_attn):
             elif m.get("fused"):   # one kernel, raw f32 features in, packed 16-bit W out: 4ND + N(N+1) algorithmic bytes
                 byts = (4.0 * m["n"] * m["d"] + 1.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-            elif os.environ.get("DSS_AFFINITY", "fused") == "fp32":   # exact fp32 MFMA build: MFMA-bound
+            elif affinity_mode == "fp32":   # exact fp32 MFMA build: MFMA-bound
                 flops = 1.0 * m["n"] * (m["n"] + 1) * m["d"] * m["b"]   # upper triangle: N(N+1)/2 dots of 2D flop
                 entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA32_PEAK_TF, unit="TFLOP/s")
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
@@ -418,16 +419,18 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
         nchunks = len(chunk_counts(cnt, a.vit_batch))
         nxt = (chunk + nchunks, chunk_counts(counts[s + 1], a.vit_batch)[0]) if s + 1 < len(counts) else None
         if a.overlap or a.vit_streams > 1:   # the opt-in variants take a whole step's images at once
-            imgs = torch.cat([feeder.get(chunk + j, n) for j, n in enumerate(chunk_counts(cnt, a.vit_batch))])
-            ev, vec, info = step(model, imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
-            for j in range(nchunks):
+            cc, parts = chunk_counts(cnt, a.vit_batch), []
+            for j, n in enumerate(cc):        # ring of NBUF buffers: the copy of chunk j + 1 goes out, chunk j is taken
+                if j + 1 < nchunks:           # (cloned: its buffer is handed back before the step reads it), then released
+                    feeder.prefetch(chunk + j + 1, cc[j + 1])
+                elif nxt is not None:
+                    feeder.prefetch(*nxt)
+                parts.append(feeder.get(chunk + j, n).clone())
                 feeder.release(chunk + j)
-                if j + 1 < nchunks:
-                    feeder.prefetch(chunk + j + 1, chunk_counts(cnt, a.vit_batch)[j + 1])
-            if nxt is not None:
-                feeder.prefetch(*nxt)
+            ev, vec, info = step(model, torch.cat(parts) if len(parts) > 1 else parts[0], a.K, a.vit_batch, a.overlap,
+                                 a.vit_streams, w_dtype, a.affinity)
         else:
-            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype)
+            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype, a.affinity)
         chunk += nchunks
         ids = (torch.arange(cnt, device=dev, dtype=torch.int64) + base) * world + rank   # global round-robin item ids
         base += cnt
@@ -474,7 +477,8 @@ def main():
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
-    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln)
+    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
+                    gemm_tuning=a.gemm_tuning)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -519,22 +523,23 @@ def main():
                 feeder.release(chunk_pos + j)
                 if j + 1 < len(cc):
                     feeder.prefetch(chunk_pos + j + 1, cc[j + 1])
-            out = step(m, torch.cat(parts), a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype)
+            out = step(m, torch.cat(parts), a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype, a.affinity)
             chunk_pos += len(cc)
             return out
-        ev, vec, info, used = step_fed(m, feeder, chunk_pos, a.batch, None, a.K, a.vit_batch, w_dtype)
+        ev, vec, info, used = step_fed(m, feeder, chunk_pos, a.batch, None, a.K, a.vit_batch, w_dtype, a.affinity)
         chunk_pos += used
         return ev, vec, info
 
     from dss_amd.vit import setup_gemm_tuning
-    setup_gemm_tuning(tune_new_shapes=True)   # warm-up may pick GEMM solutions for shapes missing from the shipped table
+    tune = a.gemm_tuning != "off"             # "off": scripts/tune_gemm.sh drives TunableOp through PyTorch's own variables
+    setup_gemm_tuning(tune_new_shapes=True, use_table=tune)   # warm-up may pick GEMM solutions for shapes missing from the table
     t_warm = time.perf_counter()
     n_warm, warm = 0, None
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
         warm = warm_step(model, a.w_dtype)
         torch.cuda.synchronize()
         n_warm += 1
-    setup_gemm_tuning(tune_new_shapes=False)  # frozen for the timed region
+    setup_gemm_tuning(tune_new_shapes=False, use_table=tune)  # frozen for the timed region
     if world > 1 and warm is None:   # --warmup 0: the collection warm-up below still needs one step's results
         warm = warm_step(model, a.w_dtype)
     if world > 1:
@@ -555,7 +560,7 @@ def main():
     for _ in range(2):    # the first call may still grow the allocator's pools (hipMalloc is synchronous): take the second
         torch.cuda.synchronize()
         t_h = time.perf_counter()
-        step(model, warm_imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+        step(model, warm_imgs, a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype, a.affinity)
         host_only_ms = min(host_only_ms, (time.perf_counter() - t_h) * 1e3)
     del warm_imgs
     torch.cuda.synchronize()
@@ -577,7 +582,7 @@ def main():
     info_all = torch.cat(infos)
     n_unconverged = int((info_all <= 0).sum().item())
     if rank == 0:
-        kern = summarize_timers(timers, n_patches, dim, depth)
+        kern = summarize_timers(timers, n_patches, dim, depth, a.affinity)
         dominant = max((k for k in kern if "achieved" in kern[k] and k != "library_gemm"), key=lambda k: kern[k]["total_ms"])
         n_forwards = sum(len(chunk_counts(c, a.vit_batch)) for c in counts)
         d = kern[dominant]
@@ -602,10 +607,10 @@ def main():
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
                        "vit_operands": "f16" if dtype == torch.float16 else "bf16", "accumulate": "fp32",
                        "affinity": {"fused": "f16 features + inverse norms from the K projection's hand-over kernel -> "
-                                             "f16-operand Gram (fp32 accumulate, 256x256 tiles, LDS-DMA panels) -> u16 W"
+                                             "f16-operand Gram (fp32 accumulate, 256x128 tiles, LDS-DMA panels) -> u16 W"
                                              if a.w_dtype == "u16" else "split-f16 (hi+lo f16 terms, fp32 accumulate)",
                                     "split": "split-f16 (hi+lo f16 terms, fp32 accumulate)",
-                                    "fp32": "exact fp32 MFMA"}[os.environ.get("DSS_AFFINITY", "fused")],
+                                    "fp32": "exact fp32 MFMA"}[a.affinity],
                        "w_dtype": "u16-fixed (round(65535 w))" if a.w_dtype == "u16" else "f32",
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
                        "h2d_in_timed_region": not a.resident, "host_page_lock": {"register": "hipHostRegister", "shm": "hipHostRegister on a /dev/shm segment", "malloc": "hipHostMalloc (tensor.pin_memory)"}[a.host_pin],
@@ -636,7 +641,7 @@ def main():
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
-                     fuse_ln=not a.no_fuse_ln)
+                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()
@@ -650,7 +655,7 @@ def main():
     if rank == 0:
         if world == 1 and a.cpu_images > 0:
             n_par = max(a.cpu_images + 1, a.parity_images)
-            first = step(model, host[:n_par].to(dev), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype)
+            first = step(model, host[:n_par].to(dev), a.K, a.vit_batch, a.overlap, a.vit_streams, a.w_dtype, a.affinity)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a.model, sd, a.size, a.K, a.cpu_images, first[1], first[0],
                                                               lam_tol=1e-3 if dtype == torch.float16 else 1e-2,
                                                               n_parity=a.parity_images)

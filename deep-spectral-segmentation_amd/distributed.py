@@ -93,7 +93,7 @@ def gather_records_to_root(meta: torch.Tensor, payload: torch.Tensor):
     and ordered by item id (``None`` on the other ranks).  Two rounds: the ``[world, 2]`` table of (records, floats)
     per rank, then point-to-point receives of exactly those sizes (all posted at once: 7 concurrent xGMI links)."""
     rank, world = rank_world()
-    if world > 1 and dist.is_initialized():
+    if dist.is_available() and dist.is_initialized():   # also with ONE rank: the sizes round then still goes through the backend
         dev = payload.device if dist.get_backend() != "gloo" else torch.device("cpu")  # gloo moves host tensors
         meta, payload = meta.to(dev).contiguous(), payload.to(dev).contiguous()
         mine = torch.tensor([meta.shape[0], payload.numel()], dtype=torch.int64, device=dev)

@@ -21,8 +21,8 @@ feature upsampling (``image_downsample_factor``) and the colour-affinity fusion 
 
 The consumers of the eigen files keep the reference's names and file formats too:
 ``extract_single_region_segmentations`` (:383-426), ``extract_multi_region_segmentations`` (:283-377),
-``extract_bboxes`` (:429-495), ``extract_bbox_features`` (:498-544), ``extract_bbox_clusters`` (:547-599) and
-``extract_semantic_segmentations`` (:602-647).
+``extract_bboxes`` (:429-495), ``extract_bbox_features`` (:498-544).  (``extract_bbox_clusters`` /
+``extract_semantic_segmentations`` / ``extract_crf_segmentations`` are outside SURVEY.md §8 and not provided.)
 """
 from __future__ import annotations
 
@@ -278,25 +278,34 @@ class _ShmBlocks:
         self.count, self.size, self.paths, self.maps, self.tensors = count, size, [], [], []
         self._sweep_stale()
 
+    STALE_AFTER_S = 6 * 3600
+
     @staticmethod
     def _sweep_stale():
-        """Blocks of runs that were killed before their ``finally`` (names carry the owner's pid): remove those whose
-        process is gone."""
+        """Blocks of runs that were killed before their ``finally`` (names carry the owner's pid): remove those that are
+        OURS (same uid), whose process is gone AND that nobody has touched for hours - /dev/shm may be shared with other
+        PID namespaces (containers started with --ipc=host), where a live run's pid looks dead from here."""
+        import time
+
         try:
             names = [n for n in os.listdir("/dev/shm") if n.startswith("dss_")]
         except OSError:
             return
+        now, uid = time.time(), os.getuid()
         for n in names:
+            path = os.path.join("/dev/shm", n)
             try:
-                pid = int(n.split("_")[1])
-                os.kill(pid, 0)          # raises if no such process
+                st = os.stat(path)
+                if st.st_uid != uid or now - max(st.st_mtime, st.st_atime) < _ShmBlocks.STALE_AFTER_S:
+                    continue
+                os.kill(int(n.split("_")[1]), 0)          # raises if no such process
             except (ProcessLookupError, ValueError, IndexError):
                 try:
-                    os.unlink(os.path.join("/dev/shm", n))
+                    os.unlink(path)
                 except OSError:
                     pass
-            except PermissionError:
-                pass                      # somebody else's live process
+            except OSError:
+                pass                      # vanished meanwhile, or somebody else's live process
 
     def add(self) -> int:
         import mmap
@@ -388,7 +397,9 @@ def _iter_features(files, which_features: str, processes: int, window: int, devi
         return
     per = 16
     chunks = [[str(f) for f in files[s:s + per]] for s in range(0, len(files), per)]
-    biggest = max(os.path.getsize(f) for f in files)    # a file's size bounds its f32 feature bytes
+    # a file's size bounds its feature bytes AS STORED; the loaders hand them over as f32: f16 / bf16 features (half the
+    # file) need twice the file's size in the block - sized for that, or half of such files would fall back to torch.load
+    biggest = 2 * max(os.path.getsize(f) for f in files)
     for entries, block, release in _pump_chunks(pthfast.load_chunk, chunks, (which_features,), processes, per * biggest):
         i = 0
         while i < len(entries):
@@ -451,6 +462,17 @@ def _shared_pinned_block(numel: int, dtype: torch.dtype) -> torch.Tensor:
     except Exception as e:  # pragma: no cover - depends on the runtime
         print(f"[dss] note: could not page-lock a shared block ({e})")
     return t
+
+
+def _release_pinned_block(t: Optional[torch.Tensor]) -> None:
+    """Undo ``_shared_pinned_block``'s registration (a block dropped while registered leaves its address range registered:
+    a later registration of reused addresses then fails and the copies fall back to pageable speed)."""
+    if t is None:
+        return
+    try:
+        torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+    except Exception:  # pragma: no cover - best effort, like the registration
+        pass
 
 
 def _shm_free_bytes() -> int:
@@ -552,12 +574,14 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     drain_err: List[BaseException] = []
 
     def drain():
-        while True:
+        torch.cuda.set_device(device)      # the current device is per THREAD: without this a rank with LOCAL_RANK != 0 would
+        while True:                        # register its blocks (and create a context) on GPU 0 from here
             job = drain_q.get()
             if job is None:
                 return
             try:
                 k_dev, done, metas = job
+                job = None                 # the queue item must not keep the batch's HBM alive past `del k_dev`
                 slot = None
                 with clock("drain: shared block"):
                     if saver.procs:
@@ -568,6 +592,7 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                         saver.wait_slot(slot)
                         need = k_dev.numel()
                         if ring["blocks"][slot] is None or ring["blocks"][slot].numel() < need:
+                            _release_pinned_block(ring["blocks"][slot])
                             ring["blocks"][slot] = _shared_pinned_block(need, k_dev.dtype)
                         k = ring["blocks"][slot][:need].view(k_dev.shape)
                     else:
@@ -633,6 +658,9 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
         raise drain_err[0]
     with clock("tail: savers finish"):
         saver.close()
+    for blk in ring["blocks"]:
+        _release_pinned_block(blk)
+    ring["blocks"] = [None] * len(ring["blocks"])
     clock.report("extract_features")
     _barrier()
     print(f"Saved features to {output_dir}")
@@ -734,10 +762,6 @@ def _run_eig_batch(items: List[Tuple[str, torch.Tensor]], K: int, normalize: boo
             torch.save(*_build_eig_file((ev_h, vec_h), (j, output_file, problem)))
     else:
         saver.submit_batch("eigs", (ev_h, vec_h), [(j, output_file, problem) for j, (output_file, _) in enumerate(items)])
-    if segment is not None and segment["grid"][0] * segment["grid"][1] > 8192 and segment.get("multi_region_dir"):
-        print(f"[dss] WARNING: {segment['grid'][0]} x {segment['grid'][1]} points exceed the on-device K-means (8192): no "
-              f"multi-region PNGs for {[Path(o).stem for o, _ in items]}; run extract_multi_region_segmentations on the eigen files")
-        segment = {**segment, "multi_region_dir": None}
     if segment is not None:
         # the segmentations of extract.py:283-426 straight from the device-resident eigenvectors,
         # no .pth round trip (same algorithms on the device: threshold of the Fiedler vector; Lloyd K-means + border vote)
@@ -811,14 +835,8 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
             if which_matrix not in ("laplacian", "matting_laplacian"):
                 raise ValueError("the on-device segmentations use eigenvector 1 of the Laplacian branches")
             Path(extra).mkdir(parents=True, exist_ok=True)
-    if multi_region_dir:
-        # limits of the on-device K-means (csrc/segment.hip: <= 32 clusters, <= 64 coordinates), checked before any work
-        dims = min(int(num_eigenvectors), int(K) - 1)
-        kmax = int(K) - 1 if adaptive else int(non_adaptive_num_segments)
-        if int(K) < 2 or dims < 1 or dims > 64 or kmax < 1 or kmax > 32:
-            raise ValueError(f"--multi_region_dir: the on-device K-means takes 1..64 eigenvector coordinates and 1..32 "
-                             f"segments (K={K}, num_eigenvectors={num_eigenvectors} -> {dims} coordinates, up to {kmax} "
-                             f"segments); lower them or run extract_multi_region_segmentations on the saved eigen files")
+    if multi_region_dir and int(K) < 2:
+        raise ValueError("--multi_region_dir clusters eigenvectors 1.. : K must be at least 2")
     kwargs = dict(K=K, which_matrix=which_matrix, which_features=which_features,
                   which_color_matrix=which_color_matrix, normalize=normalize, threshold_at_zero=threshold_at_zero,
                   images_root=images_root, output_dir=output_dir, image_downsample_factor=image_downsample_factor,
@@ -865,9 +883,12 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         output_file = str(Path(output_dir) / f"{image_id}.pth")
         # the reference writes synchronously, so a second feature file naming the same image finds the first one's
         # output and is skipped (extract.py:141-146); here the first may still be in flight: remember what is scheduled
-        if output_file in scheduled or Path(output_file).is_file():
+        pngs_there = all(Path(dd, f"{image_id}.png").is_file() for dd in (single_region_dir, multi_region_dir) if dd)
+        if output_file in scheduled or (Path(output_file).is_file() and pngs_there):
             print(f"Skipping existing file {str(output_file)}")
             continue
+        if Path(output_file).is_file():   # an earlier run wrote the eigen file but not the requested PNGs: redo both
+            print(f"[dss] {image_id}: eigen file exists but a requested segmentation PNG does not - recomputing")
         scheduled.add(output_file)
         problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
                                      data_dict["patch_size"])
@@ -894,24 +915,39 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     _barrier()
 
 
-def _extract_single_region_segmentations(inp: Tuple[int, Tuple[str, str]], threshold: float, output_dir: str):
-    """Immediate consumer of the eigen files (reference extract/extract.py:383-407): the
-    patch-level foreground mask ``eigenvectors[1] > threshold`` reshaped ``(H//P, W//P)``, saved as an 8-bit PNG
-    (0 / 255).  Pure host-side bookkeeping - no kernel involved."""
+# ------------------------------------------------------------------------------------------ consumers of the eigen files
+# SURVEY.md §8f rows 1-2.  The commands keep the reference's names, flags, defaults, file pairing and outputs; the work
+# itself runs on the device kernels the in-memory pipeline uses (`extract_eigs --single_region_dir / --multi_region_dir`
+# writes the same PNGs without the .pth round trip).
+
+def _segmentation_job(pair, output_dir: str):
+    """One paired (feature file, eigen file) -> ``(png path, (rows, cols) of the patch grid, feature dict, eigen dict)``;
+    ``None`` (with the reference's message) when the PNG is already there."""
+    feature_path, eigs_path = pair
+    meta = torch.load(feature_path, map_location="cpu", weights_only=False)
+    target = Path(output_dir) / f"{Path(meta['id'])}.png"
+    if target.is_file():
+        print(f"Skipping existing file {str(target)}")
+        return None
+    sizes = utils.get_image_sizes(meta)
+    return target, (int(sizes[5]), int(sizes[6])), meta, torch.load(eigs_path, map_location="cpu", weights_only=False)
+
+
+def _save_label_png(labels: torch.Tensor, target: Path) -> None:
     from PIL import Image
 
-    index, (feature_path, eigs_path) = inp
-    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
-    data_dict.update(torch.load(eigs_path, map_location="cpu", weights_only=False))
-    output_file = str(Path(output_dir) / f"{Path(data_dict['id'])}.png")
-    if Path(output_file).is_file():
-        print(f"Skipping existing file {str(output_file)}")
+    Image.fromarray(labels.to("cpu", torch.uint8).numpy(), mode="L").save(str(target))
+
+
+def _extract_single_region_segmentations(inp: Tuple[int, Tuple[str, str]], threshold: float, output_dir: str):
+    """reference extract/extract.py:383-407: the 0 / 255 mask of ``eigenvectors[1] > threshold`` on the ``(H//P, W//P)``
+    grid, from ``dss_fiedler_mask``."""
+    job = _segmentation_job(inp[1], output_dir)
+    if job is None:
         return
-    sizes = utils.get_image_sizes(data_dict)
-    h_patch, w_patch = sizes[5], sizes[6]
-    fiedler = data_dict["eigenvectors"][1].numpy()  # smallest non-trivial eigenvector
-    segmap = (fiedler > threshold).reshape(h_patch, w_patch)
-    Image.fromarray(segmap).convert("L").save(output_file)
+    target, (rows, cols), _, eig = job
+    vec = eig["eigenvectors"].to(local_device(), torch.float32)[None]
+    _save_label_png(spectral.single_region_masks(vec, threshold)[0].view(rows, cols), target)
 
 
 def extract_single_region_segmentations(features_dir: str, eigs_dir: str, output_dir: str, threshold: float = 0.0,
@@ -924,48 +960,38 @@ def extract_single_region_segmentations(features_dir: str, eigs_dir: str, output
 
 def _extract_multi_region_segmentations(inp: Tuple[int, Tuple[str, str]], adaptive: bool, non_adaptive_num_segments: int,
                                         infer_bg_index: bool, kmeans_baseline: bool, output_dir: str,
-                                        num_eigenvectors: int):
-    """One (feature file, eigen file) pair -> one label PNG (reference extract/extract.py:283-352): K-means over the
-    non-constant eigenvectors (or, ``kmeans_baseline``, over the raw features); ``adaptive`` picks the number of segments
-    from the largest eigengap; ``infer_bg_index`` renames the segment owning most of the border to 0.  Host-side: the
-    clustering is ``sklearn.cluster.KMeans`` exactly as in the reference (N <= a few thousand points in <= K - 1
-    dimensions), so that a seeded run reproduces the reference's labels."""
-    import numpy as np
-    from PIL import Image
-    from sklearn.cluster import KMeans
-
-    index, (feature_path, eigs_path) = inp
-    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
-    data_dict.update(torch.load(eigs_path, map_location="cpu", weights_only=False))
-    output_file = str(Path(output_dir) / f"{Path(data_dict['id'])}.png")
-    if Path(output_file).is_file():
-        print(f"Skipping existing file {str(output_file)}")
+                                        num_eigenvectors: int, seed: int = 0):
+    """reference extract/extract.py:283-352: label map of a K-means over the non-constant eigenvectors (``adaptive``: as
+    many segments as the largest eigengap says; ``infer_bg_index``: the segment owning the border becomes 0), on the
+    patch grid or - eigenvectors of the 2x upsampled grid - on twice that.  Clustering, border vote and label swap are
+    ``dss_kmeans_segments`` (one workgroup per image); problems beyond its limits (more than 8192 points, 64 coordinates or
+    32 segments) and the ``kmeans_baseline`` (raw features as coordinates) take ``spectral.kmeans_lloyd`` on the device.
+    The reference's ``KMeans()`` is unseeded - its labels are a random variable; here ``seed`` fixes them."""
+    job = _segmentation_job(inp[1], output_dir)
+    if job is None:
         return
-    sizes = utils.get_image_sizes(data_dict)
-    h_patch, w_patch = sizes[5], sizes[6]
-    if adaptive:   # the largest eigengap, not counting the one after eigenvalue 0
-        indices_by_gap = np.argsort(np.diff(data_dict["eigenvalues"].numpy()))[::-1]
-        n_clusters = int(indices_by_gap[indices_by_gap != 0][0]) + 1
-    else:
-        n_clusters = non_adaptive_num_segments
-    kmeans = KMeans(n_clusters=n_clusters)
+    target, (rows, cols), meta, eig = job
+    dev = local_device()
+    lam = eig["eigenvalues"].to(dev, torch.float32)[None]
+    vec = eig["eigenvectors"].to(dev, torch.float32)[None]
+    points = vec.shape[-1]
+    scale = {rows * cols: 1, 4 * rows * cols: 2}.get(points)
+    if scale is None:
+        raise ValueError(f"{meta['id']}: {points} eigenvector entries for a {rows} x {cols} patch grid")
+    grid = (scale * rows, scale * cols)
     if kmeans_baseline:
-        clusters = kmeans.fit_predict(data_dict["k"].squeeze().numpy())
+        feats = meta["k"].to(dev, torch.float32).reshape(-1, meta["k"].shape[-1])
+        if feats.shape[0] != points:
+            raise ValueError(f"{meta['id']}: kmeans_baseline needs one feature row per eigenvector entry")
+        k = spectral.adaptive_num_segments(lam)[0] if adaptive else int(non_adaptive_num_segments)
+        labels = spectral.kmeans_lloyd(feats, k, seed=seed).view(grid)
+        if infer_bg_index:
+            labels = spectral.border_owner_to_zero(labels)
     else:
-        clusters = kmeans.fit_predict(data_dict["eigenvectors"][1:1 + num_eigenvectors].numpy().T)
-    if clusters.size == h_patch * w_patch:
-        segmap = clusters.reshape(h_patch, w_patch)
-    elif clusters.size == h_patch * w_patch * 4:   # eigenvectors computed on the 2x upsampled grid
-        segmap = clusters.reshape(h_patch * 2, w_patch * 2)
-    else:
-        raise ValueError()
-    if infer_bg_index:   # swap labels: the segment with the most border pixels becomes 0
-        indices, normalized_counts = utils.get_border_fraction(segmap)
-        bg_index = indices[np.argmax(normalized_counts)].item()
-        bg_region, zero_region = (segmap == bg_index), (segmap == 0)
-        segmap[bg_region] = 0
-        segmap[zero_region] = bg_index
-    Image.fromarray(segmap).convert("L").save(output_file)
+        labels = spectral.multi_region_segments(lam, vec, grid, adaptive=adaptive, infer_bg_index=infer_bg_index,
+                                                non_adaptive_num_segments=non_adaptive_num_segments,
+                                                num_eigenvectors=num_eigenvectors, seed=seed)[0]
+    _save_label_png(labels, target)
 
 
 def extract_multi_region_segmentations(features_dir: str, eigs_dir: str, output_dir: str, adaptive: bool = False,
@@ -982,29 +1008,19 @@ def extract_multi_region_segmentations(features_dir: str, eigs_dir: str, output_
 
 def _extract_bbox(inp: Tuple[int, Tuple[str, str]], num_erode: int, num_dilate: int, skip_bg_index: bool,
                   downsample_factor: Optional[int] = None) -> dict:
-    """One (feature file, segmentation PNG) pair -> the boxes of its segments (reference extract/extract.py:429-470):
-    every label (0 = background skipped unless asked) is eroded ``num_erode`` times, dilated ``num_dilate`` times, and
-    boxed ``(xmin, ymin, xmax, ymax)`` with exclusive maxima, in segmentation-grid units and times ``P`` in pixels."""
+    """reference extract/extract.py:429-470: the box of every segment of a label PNG after ``num_erode`` erosions and
+    ``num_dilate`` dilations (``utils.segment_boxes``), ``(xmin, ymin, xmax, ymax)`` with exclusive maxima, in grid units
+    and - times the patch size (or ``downsample_factor``) - in pixels.  Schema of the per-image dict: SURVEY.md §8f."""
     import numpy as np
     from PIL import Image
 
-    index, (feature_path, segmentation_path) = inp
-    data_dict = torch.load(feature_path, map_location="cpu", weights_only=False)
-    segmap = np.array(Image.open(str(segmentation_path)))
-    p = utils.get_image_sizes(data_dict, downsample_factor)[4]
-    outputs = {"bboxes": [], "bboxes_original_resolution": [], "segment_indices": [], "id": data_dict["id"],
-               "format": "(xmin, ymin, xmax, ymax)"}
-    for segment_index in sorted(np.unique(segmap).tolist()):
-        if skip_bg_index and not segment_index > 0:
-            continue
-        binary_mask = utils.erode_or_dilate_mask(segmap == segment_index, r=num_erode, erode=True)
-        binary_mask = utils.erode_or_dilate_mask(binary_mask, r=num_dilate, erode=False)
-        ys, xs = np.where(binary_mask == 1)
-        bbox = [int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1]
-        outputs["segment_indices"].append(segment_index)
-        outputs["bboxes"].append(bbox)
-        outputs["bboxes_original_resolution"].append([v * p for v in bbox])
-    return outputs
+    feature_path, segmentation_path = inp[1]
+    meta = torch.load(feature_path, map_location="cpu", weights_only=False)
+    unit = int(utils.get_image_sizes(meta, downsample_factor)[4])
+    labels, boxes = utils.segment_boxes(np.asarray(Image.open(str(segmentation_path))), num_erode, num_dilate,
+                                        include_background=not skip_bg_index)
+    return {"bboxes": boxes, "bboxes_original_resolution": [[unit * v for v in box] for box in boxes],
+            "segment_indices": labels, "id": meta["id"], "format": "(xmin, ymin, xmax, ymax)"}
 
 
 def extract_bboxes(features_dir: str, segmentations_dir: str, output_file: str, num_erode: int = 2, num_dilate: int = 3,
@@ -1012,10 +1028,8 @@ def extract_bboxes(features_dir: str, segmentations_dir: str, output_file: str, 
     """python extract.py extract_bboxes --features_dir F --segmentations_dir S --num_erode 2 --num_dilate 5
     --output_file bboxes.pth   (one list of per-image dicts in ONE file, reference extract/extract.py:473-495)"""
     utils.make_output_dir(str(Path(output_file).parent), check_if_empty=False)
-    fn = partial(_extract_bbox, num_erode=num_erode, num_dilate=num_dilate, skip_bg_index=skip_bg_index,
-                 downsample_factor=downsample_factor)
-    all_outputs = [fn(inp) for inp in utils.get_paired_input_files(features_dir, segmentations_dir)]
-    torch.save(all_outputs, output_file)
+    pairs = utils.get_paired_input_files(features_dir, segmentations_dir)
+    torch.save([_extract_bbox(pair, num_erode, num_dilate, skip_bg_index, downsample_factor) for pair in pairs], output_file)
     print("Done")
 
 
@@ -1050,74 +1064,11 @@ def extract_bbox_features(images_root: str, bbox_file: str, model_name: str, out
     print(f"Saved features to {output_file}")
 
 
-def extract_bbox_clusters(bbox_features_file: str, output_file: str, num_clusters: int = 20, seed: int = 0,
-                          pca_dim: Optional[int] = 0):
-    """python extract.py extract_bbox_clusters --bbox_features_file F --pca_dim 32 --num_clusters 21 --seed 0
-    --output_file O   (reference extract/extract.py:547-599): L2-normalise the box features of the whole dataset, optional
-    PCA, MiniBatchKMeans - sklearn with the reference's own parameters, so a given ``seed`` reproduces its clusters -
-    and write the list back with ``'clusters'`` in place of ``'features'``.  Host side: a few thousand boxes."""
-    import numpy as np
-    from sklearn.cluster import MiniBatchKMeans
-    from sklearn.decomposition import PCA
-
-    bbox_list = torch.load(bbox_features_file, weights_only=False)
-    total_num_boxes = sum(len(d["bboxes"]) for d in bbox_list)
-    print(f"Loaded bounding box list. There are {total_num_boxes} total bounding boxes with features.")
-    all_features = torch.cat([d["features"] for d in bbox_list], dim=0)
-    all_features = (all_features / torch.norm(all_features, dim=-1, keepdim=True)).numpy()
-    if pca_dim:
-        print(f"Computing PCA with dimension {pca_dim}")
-        all_features = PCA(pca_dim).fit_transform(all_features)
-    print(f"Computing K-Means clustering with {num_clusters} clusters")
-    kmeans = MiniBatchKMeans(n_clusters=num_clusters, batch_size=4096, max_iter=5000, random_state=seed)
-    clusters = kmeans.fit_predict(all_features)
-    _indices, _counts = np.unique(clusters, return_counts=True)
-    print(f"Cluster indices: {_indices.tolist()}")
-    print(f"Cluster counts: {_counts.tolist()}")
-    idx = 0
-    for bbox_dict in bbox_list:
-        num_bboxes = len(bbox_dict["bboxes"])
-        del bbox_dict["features"]
-        bbox_dict["clusters"] = clusters[idx: idx + num_bboxes]
-        idx += num_bboxes
-    torch.save(bbox_list, output_file)
-    print(f"Saved features to {output_file}")
-
-
-def extract_semantic_segmentations(segmentations_dir: str, bbox_clusters_file: str, output_dir: str):
-    """python extract.py extract_semantic_segmentations --segmentations_dir S --bbox_clusters_file C --output_dir O
-    (reference extract/extract.py:602-647): every segment of a multi-region map takes the cluster id of its box; segment 0
-    (background) stays 0; a 0 / 255 binary map counts as 0 / 1."""
-    import numpy as np
-    from PIL import Image
-
-    bbox_list = torch.load(bbox_clusters_file, weights_only=False)
-    total_num_boxes = sum(len(d["bboxes"]) for d in bbox_list)
-    print(f"Loaded bounding box list. There are {total_num_boxes} total bounding boxes with features and clusters.")
-    utils.make_output_dir(output_dir)
-    for bbox_dict in bbox_list:
-        image_id = bbox_dict["id"]
-        segmap = np.array(Image.open(str(Path(segmentations_dir) / f"{image_id}.png")))
-        if set(np.unique(segmap).tolist()).issubset({0, 255}):
-            segmap[segmap == 255] = 1
-        clusters = np.asarray(bbox_dict["clusters"]).tolist()
-        if len(bbox_dict["segment_indices"]) != len(clusters):   # the reference drops into pdb here
-            raise ValueError(f"{image_id}: {len(bbox_dict['segment_indices'])} segments but {len(clusters)} clusters")
-        semantic_map = dict(zip(bbox_dict["segment_indices"], clusters))
-        assert 0 not in semantic_map, semantic_map
-        semantic_map[0] = 0
-        semantic_segmap = np.vectorize(semantic_map.__getitem__)(segmap)
-        Image.fromarray(semantic_segmap.astype(np.uint8)).convert("L").save(str(Path(output_dir) / f"{image_id}.png"))
-    print(f"Saved features to {output_dir}")
-
-
 # ------------------------------------------------------------------------------------------ CLI
 COMMANDS = dict(extract_features=extract_features, extract_eigs=extract_eigs,
                 extract_single_region_segmentations=extract_single_region_segmentations,
                 extract_multi_region_segmentations=extract_multi_region_segmentations,
-                extract_bboxes=extract_bboxes, extract_bbox_features=extract_bbox_features,
-                extract_bbox_clusters=extract_bbox_clusters,
-                extract_semantic_segmentations=extract_semantic_segmentations)
+                extract_bboxes=extract_bboxes, extract_bbox_features=extract_bbox_features)
 
 
 def _literal(s: str):

@@ -206,6 +206,21 @@ def erode_or_dilate_mask(x, r: int = 0, erode: bool = True):
     return x
 
 
+def segment_boxes(segmap: np.ndarray, num_erode: int, num_dilate: int, include_background: bool = False):
+    """Label map -> ``(labels, boxes)``: for every label present (ascending; 0 only with ``include_background``) its mask is
+    eroded ``num_erode`` and dilated ``num_dilate`` times (``erode_or_dilate_mask``: never to nothing) and boxed as
+    ``[xmin, ymin, xmax + 1, ymax + 1]`` (reference extract/extract.py:443-458)."""
+    labels, boxes = [], []
+    for label in np.unique(segmap).tolist():
+        if label <= 0 and not include_background:
+            continue
+        mask = erode_or_dilate_mask(erode_or_dilate_mask(segmap == label, num_erode, erode=True), num_dilate, erode=False)
+        cols, rows = np.flatnonzero(mask.any(axis=0)), np.flatnonzero(mask.any(axis=1))
+        labels.append(label)
+        boxes.append([int(cols[0]), int(rows[0]), int(cols[-1]) + 1, int(rows[-1]) + 1])
+    return labels, boxes
+
+
 def get_border_fraction(segmap: np.ndarray):
     """``(labels, fraction of the 2 (H + W) border pixels carrying each label)`` - corner pixels count twice, labels in
     ascending order (reference extract_utils.py:124-135)."""

@@ -395,7 +395,7 @@ def affinity_fused_u16(feats: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
 
 def affinity_f16_u16(feats16: torch.Tensor, rnorm: torch.Tensor) -> torch.Tensor:
     """f16 ``[B, N, D]`` features + inverse row norms ``[B, N]`` (``kfeatures_finalize``) -> the packed 16-bit W of
-    ``affinity_fused_u16`` (``dss_affinity_f16_u16``: 256 x 256 tiles, panels by LDS-DMA)."""
+    ``affinity_fused_u16`` (``dss_affinity_f16_u16``: 256 x 128 tiles, panels by LDS-DMA)."""
     assert feats16.dtype == torch.float16 and feats16.dim() == 3 and rnorm.dtype == torch.float32
     b, n, d = feats16.shape
     assert rnorm.numel() == b * n

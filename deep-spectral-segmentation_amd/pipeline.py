@@ -5,7 +5,6 @@ This is ``extract_features`` followed by ``extract_eigs`` without the ``.pth`` r
 this in-memory form)."""
 from __future__ import annotations
 
-import os
 from typing import Tuple
 
 import torch
@@ -17,10 +16,12 @@ from .vit import DinoViT
 @torch.no_grad()
 def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block: int = -1,
                       normalize: bool = True, threshold_at_zero: bool = True,
-                      strict: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                      strict: bool = True, affinity_mode: str = "fused"
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """``img_u8`` u8 ``[B, H, W, 3]`` on the GPU -> (k ``[B, N, D]``, eigenvalues ``[B, K]``,
-    eigenvectors ``[B, K, N]``, info ``[B]``)."""
-    mode = os.environ.get("DSS_AFFINITY", "fused")
+    eigenvectors ``[B, K, N]``, info ``[B]``).  ``affinity_mode``: ``spectral.laplacian_eigs_from_features``'s (default
+    here ``"fused"``, see below; ``"split"`` / ``"fp32"`` are the A/B arms)."""
+    mode = affinity_mode
     k16 = rn = None
     if mode == "fused" and normalize and threshold_at_zero:
         k, k16, rn = model.extract_k_f16(img_u8, which_block=which_block)
@@ -29,7 +30,7 @@ def features_and_eigs(model: DinoViT, img_u8: torch.Tensor, K: int, which_block:
     # the features just came out of the half-precision ViT (relative error ~1e-3): the fused affinity build, which rounds
     # them to f16 (2^-11) on its way into the MFMAs, costs nothing in accuracy here.  Its own tolerance, for callers with
     # EXACT fp32 features: |dW| <= 5e-5, eigenvalues within ~6e-5 of the fp32 build - looser than the 1e-5 eigenvalue bar
-    # `extract_eigs` holds on .pth features, which is why that command uses the 'split' build (DSS_AFFINITY=split here);
+    # `extract_eigs` holds on .pth features, which is why that command uses the 'split' build (affinity_mode="split" here);
     # end to end (f16 ViT + this build) the eigenvalues are within 1e-3, the eigenvectors within 1e-6 in cosine of the
     # all-fp32 CPU path (bench.py `parity`, eigenvalue_tol 1e-3).
     ev, vec, info = spectral.laplacian_eigs_from_features(k, K, normalize=normalize,
@@ -45,8 +46,9 @@ class OverlappedExtractor:
     Results are identical to ``features_and_eigs`` (same kernels, same order per image)."""
 
     def __init__(self, model: DinoViT, K: int, vit_batch: int = 128, which_block: int = -1,
-                 normalize: bool = True, threshold_at_zero: bool = True):
+                 normalize: bool = True, threshold_at_zero: bool = True, affinity_mode: str = "fused"):
         self.model, self.K, self.vit_batch, self.which_block = model, K, vit_batch, which_block
+        self.affinity_mode = affinity_mode
         self.normalize, self.threshold_at_zero = normalize, threshold_at_zero
         self.side = torch.cuda.Stream(device=model.device)
 
@@ -64,7 +66,7 @@ class OverlappedExtractor:
                 k.record_stream(self.side)
                 outs.append(spectral.laplacian_eigs_from_features(
                     k, self.K, normalize=self.normalize, threshold_at_zero=self.threshold_at_zero, strict=False,
-                    retry=False, affinity_mode=os.environ.get("DSS_AFFINITY", "fused")))
+                    retry=False, affinity_mode=self.affinity_mode))
             if keep_features:
                 feats.append(k)
         main.wait_stream(self.side)

@@ -7,7 +7,6 @@ device->host copy and no scipy.
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -95,10 +94,10 @@ def reference_scale(problem: str, wmax: torch.Tensor, ev: torch.Tensor, vec: tor
 def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = True,
                                  threshold_at_zero: bool = True, ncv: int = 0, tol: float = 0.0,
                                  max_restarts: int = 0, max_bytes: int = 24 << 30, strict: bool = True,
-                                 affinity_mode: Optional[str] = None, retry: bool = True,
+                                 affinity_mode: str = "split", retry: bool = True,
                                  problem: str = "laplacian",
                                  upsample: Optional[Tuple[Tuple[int, int], Tuple[int, int]]] = None,
-                                 w_dtype: Optional[str] = None,
+                                 w_dtype: str = "u16",
                                  feats16: Optional[torch.Tensor] = None, rnorm: Optional[torch.Tensor] = None
                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``feats``: f32 ``[B, N, D]`` on the GPU (one row per patch).  Returns
@@ -114,14 +113,14 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     * ``upsample``: ``((H_patch, W_patch), (H_lr, W_lr))`` - the reference's feature upsampling when
       ``image_downsample_factor != patch_size`` (extract.py:179-188): the (already normalised) features are resized
       bilinearly (``align_corners=False``) from the patch grid to the low-resolution pixel grid before the affinity.
-    * ``affinity_mode`` (``$DSS_AFFINITY``): ``"split"`` (default) builds W with two-term split-f16 MFMAs (error ~1e-7:
+    * ``affinity_mode``: ``"split"`` (default) builds W with two-term split-f16 MFMAs (error ~1e-7:
       what ``extract_eigs`` needs for fp32 features read from ``.pth`` files - eigenvalues within 1e-5 of the reference);
       ``"fp32"`` uses exact fp32 MFMAs; ``"fused"`` = for the default recipe with 16-bit W and ``D >= 256``, ONE kernel from
       raw features to packed W with f16 MFMA operands (``|dW| <= ~5e-5``, eigenvalues within ~6e-5, eigenvectors within
       ~1e-5 in cosine) - free when the features come out of the half-precision ViT, which is where ``pipeline`` and
       ``bench.py`` use it - and the split build otherwise.  With the default recipe (``problem="laplacian"``,
-      ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``w_dtype="f32"`` /
-      ``$DSS_W_DTYPE=f32`` keeps floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
+      ``normalize``, ``threshold_at_zero``) W is stored as ``round(65535 w)`` in 16 bits (``w_dtype="f32"``
+      keeps floats): the problem is scale-invariant and the eigenvectors move by <= 1e-6 in cosine.
     * ``feats16`` / ``rnorm``: the f16 copy of ``feats`` and its inverse row norms (``hip.kfeatures_finalize``: the
       hand-over of a ViT that ran just before, ``DinoViT.extract_k_f16``).  With them the ``"fused"`` build of the
       default recipe starts from the f16 rows (``hip.affinity_f16_u16``: half the bytes through the L2, panels by
@@ -134,8 +133,6 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     if feats.dim() == 2:
         feats = feats[None]
     assert feats.dim() == 3 and feats.dtype == torch.float32
-    if affinity_mode is None:
-        affinity_mode = os.environ.get("DSS_AFFINITY", "split")
     if affinity_mode not in ("fused", "split", "fp32"):
         raise ValueError(f"affinity_mode must be 'fused', 'split' or 'fp32' (got {affinity_mode!r})")
     b, n, d = feats.shape
@@ -169,8 +166,6 @@ def laplacian_eigs_from_features(feats: torch.Tensor, K: int, normalize: bool = 
     # W as 16-bit fixed point (half the bytes of the solver's only HBM stream) whenever the problem allows it: the
     # normalised Laplacian is invariant to the scale of W, and normalised + thresholded similarities lie in [0, 1]
     # (after an upsample the rows are interpolated, not re-normalised: |w| <= 1 still holds, but keep f32 there).
-    if w_dtype is None:
-        w_dtype = os.environ.get("DSS_W_DTYPE", "u16")
     if w_dtype not in ("u16", "f32"):
         raise ValueError(f"w_dtype must be 'u16' or 'f32' (got {w_dtype!r})")
     w_u16 = (problem == "laplacian" and normalize and threshold_at_zero and upsample is None and d % 32 == 0
@@ -298,33 +293,85 @@ def single_region_masks(eigenvectors: torch.Tensor, threshold: float = 0.0) -> t
     return hip.fiedler_mask(eigenvectors, 1, threshold)
 
 
+def adaptive_num_segments(eigenvalues: torch.Tensor) -> List[int]:
+    """``[B, K]`` ascending eigenvalues -> per image, one more than the position of the largest gap between consecutive
+    eigenvalues, the gap behind eigenvalue 0 not counted (extract.py:306-309)."""
+    gaps = torch.diff(eigenvalues.float(), dim=1)
+    gaps[:, 0] = float("-inf")
+    return (gaps.argmax(dim=1) + 1).tolist()
+
+
+def border_owner_to_zero(labels: torch.Tensor) -> torch.Tensor:
+    """``[rows, cols]`` integer labels -> the same map with the label that covers most of the image border exchanged with
+    label 0 (the reference's background rule, extract.py:341-346 with extract_utils.py:124-135: the four border lines are
+    concatenated, so corners count twice; ties go to the smaller label)."""
+    border = torch.cat((labels[:, 0], labels[:, -1], labels[0, :], labels[-1, :])).long()
+    owner = int(torch.bincount(border).argmax())
+    out = labels.clone()
+    out[labels == owner] = 0
+    out[labels == 0] = owner
+    return out
+
+
+@torch.no_grad()
+def kmeans_lloyd(points: torch.Tensor, k: int, seed: int = 0, max_iter: int = 300, tol: float = 1e-4) -> torch.Tensor:
+    """Plain Lloyd K-means on the device for what ``dss_kmeans_segments`` does not take (more than 8192 points / 64
+    coordinates / 32 clusters; the reference's ``kmeans_baseline`` over raw 384-d features): k-means++ seeding from a
+    seeded generator, iterations until the labels repeat or the squared centre shift is below ``tol`` x the mean
+    coordinate variance (sklearn's two rules).  ``points [N, d]`` f32 -> ``[N]`` int64 labels."""
+    n, _ = points.shape
+    k = max(1, min(int(k), n))
+    gen = torch.Generator(device="cpu").manual_seed(int(seed))
+    centres = points[torch.randint(n, (1,), generator=gen)]
+    d2 = torch.cdist(points, centres).square().amin(dim=1)
+    while centres.shape[0] < k:                                   # k-means++: next centre drawn proportionally to D^2
+        total = float(d2.sum())
+        pick = int(torch.searchsorted(torch.cumsum(d2, 0), torch.rand((), generator=gen).item() * total).clamp(max=n - 1)) \
+            if total > 0 else int(torch.randint(n, (1,), generator=gen))
+        centres = torch.cat((centres, points[pick:pick + 1]))
+        d2 = torch.minimum(d2, (points - points[pick]).square().sum(dim=1))
+    bar = tol * float(points.var(dim=0, unbiased=False).mean())
+    labels = torch.full((n,), -1, dtype=torch.long, device=points.device)
+    for _ in range(max_iter):
+        new_labels = torch.cdist(points, centres).argmin(dim=1)
+        sums = torch.zeros_like(centres).index_add_(0, new_labels, points)
+        counts = torch.bincount(new_labels, minlength=k).unsqueeze(1)
+        new_centres = torch.where(counts > 0, sums / counts.clamp(min=1), centres)     # an empty cluster keeps its centre
+        shift = float((new_centres - centres).square().sum())
+        done = bool((new_labels == labels).all()) or shift <= bar
+        labels, centres = new_labels, new_centres
+        if done:
+            break
+    return torch.cdist(points, centres).argmin(dim=1)
+
+
 @torch.no_grad()
 def multi_region_segments(eigenvalues: torch.Tensor, eigenvectors: torch.Tensor, grid: Tuple[int, int],
                           adaptive: bool = False, non_adaptive_num_segments: int = 4, infer_bg_index: bool = True,
                           num_eigenvectors: int = 1_000_000, init: Optional[torch.Tensor] = None, seed: int = 0):
-    """extract.py:283-352 on the device, without the ``.pth`` round trip: K-means over ``eigenvectors[b, 1:1+num_eigenvectors].T``
-    (``hip.kmeans_segments``: Lloyd + sklearn's stopping rules; ``init`` ``[B, k, dims]`` or k-means++ from ``seed``), the
-    number of segments fixed or - ``adaptive`` - one more than the index of the largest eigengap not counting the first,
-    then the border vote that renames the segment owning most of the border to 0.  ``grid`` = (rows, cols) of the
-    eigenvectors' patch grid.  Returns u8 labels ``[B, rows, cols]``.  (The CLI command of the same name clusters with
-    sklearn on the host exactly as the reference does; this is the same algorithm for device-resident pipelines -
-    the partitions agree, the label numbering before the border vote depends on the initial centres in both.)"""
+    """extract.py:283-352 on the device: K-means over ``eigenvectors[b, 1:1+num_eigenvectors].T`` (``hip.kmeans_segments``:
+    Lloyd + sklearn's stopping rules; ``init`` ``[B, k, dims]`` or k-means++ from ``seed``), the number of segments fixed or
+    - ``adaptive`` - from the largest eigengap, then the border vote that renames the segment owning most of the border to
+    0.  ``grid`` = (rows, cols) of the eigenvectors' patch grid.  Returns u8 labels ``[B, rows, cols]``.  Both the CLI
+    command and ``extract_eigs --multi_region_dir`` come through here; images beyond the kernel's limits (8192 points, 64
+    coordinates, 32 segments) take ``kmeans_lloyd`` + ``border_owner_to_zero``.  The reference's ``KMeans()`` is unseeded:
+    partitions agree with it up to K-means' dependence on the initial centres."""
     b, k, n = eigenvectors.shape
     assert grid[0] * grid[1] == n, (grid, n)
     dims = min(int(num_eigenvectors), k - 1)
     out = torch.empty((b, n), dtype=torch.uint8, device=eigenvectors.device)
-    if adaptive:
-        gaps = torch.diff(eigenvalues.float(), dim=1)
-        gaps[:, 0] = float("-inf")                      # "remove zero and take the biggest"
-        ks = (gaps.argmax(dim=1) + 1).tolist()
-    else:
-        ks = [int(non_adaptive_num_segments)] * b
+    ks = adaptive_num_segments(eigenvalues) if adaptive else [int(non_adaptive_num_segments)] * b
     for kk in sorted(set(ks)):
         idx = [i for i, v in enumerate(ks) if v == kk]
         sel = torch.tensor(idx, device=eigenvectors.device)
-        lab, _, _ = hip.kmeans_segments(eigenvectors[sel].contiguous(), kk, first=1, dims=dims, grid=grid,
-                                        infer_bg=infer_bg_index, init=None if init is None else init[sel], seed=seed)
-        out[sel] = lab
+        if n <= 8192 and 1 <= dims <= 64 and 1 <= kk <= 32:
+            lab, _, _ = hip.kmeans_segments(eigenvectors[sel].contiguous(), kk, first=1, dims=dims, grid=grid,
+                                            infer_bg=infer_bg_index, init=None if init is None else init[sel], seed=seed)
+            out[sel] = lab
+        else:
+            for i in idx:
+                lab = kmeans_lloyd(eigenvectors[i, 1:1 + dims].t().contiguous(), kk, seed=seed).view(grid)
+                out[i] = (border_owner_to_zero(lab) if infer_bg_index else lab).reshape(-1).to(torch.uint8)
     return out.view(b, grid[0], grid[1])
 
 

@@ -35,19 +35,18 @@ _TUNING_FILE = Path(__file__).resolve().parent / "tuning" / "tunableop_gfx950.cs
 _gemm_tuning_ready = False
 
 
-def setup_gemm_tuning(tune_new_shapes: Optional[bool] = None) -> None:
-    """The Linear layers not covered by ``dss_linear_k384`` are hipBLASLt GEMMs issued through PyTorch.  PyTorch's TunableOp picks, per GEMM
+def setup_gemm_tuning(tune_new_shapes: bool = False, use_table: bool = True) -> None:
+    """The Linear layers not covered by the K-resident kernels are hipBLASLt GEMMs issued through PyTorch.  PyTorch's TunableOp picks, per GEMM
     shape, the fastest hipBLASLt/rocBLAS solution; the table measured on MI355X for the bench shapes ships in
     ``tuning/tunableop_gfx950.csv`` (+5 % end to end over the default heuristic).  Shapes not in the table use
-    the default heuristic unless ``tune_new_shapes`` (or ``DSS_GEMM_TUNE=1``) asks for on-line tuning
-    (~3 s per new shape, once)."""
+    the default heuristic unless ``tune_new_shapes`` asks for on-line tuning (~3 s per new shape, once).
+    ``use_table=False`` leaves TunableOp alone altogether (scripts/tune_gemm.sh drives it through PyTorch's own
+    ``PYTORCH_TUNABLEOP_*`` variables to PRODUCE the table)."""
     global _gemm_tuning_ready
-    import os
-
+    if not use_table:
+        return
     tun = torch.cuda.tunable
     if not _gemm_tuning_ready:
-        if os.environ.get("DSS_GEMM_TUNE", "") == "off":
-            return
         tun.enable(True)
         if hasattr(tun, "write_file_on_exit"):
             tun.write_file_on_exit(False)  # never rewrite the shipped table behind the user's back
@@ -58,8 +57,6 @@ def setup_gemm_tuning(tune_new_shapes: Optional[bool] = None) -> None:
             except Exception as e:  # a table from another ROCm build is ignored, not fatal
                 print(f"[dss] ignoring GEMM tuning table {_TUNING_FILE.name}: {e}")
         _gemm_tuning_ready = True
-    if tune_new_shapes is None:
-        tune_new_shapes = os.environ.get("DSS_GEMM_TUNE", "") == "1"
     tun.tuning_enable(bool(tune_new_shapes))
 
 
@@ -87,7 +84,7 @@ class DinoViT:
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
-                 linear_kres: int = 2, fuse_ln: bool = True):
+                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table"):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -163,7 +160,9 @@ class DinoViT:
         self.scale = 64 ** -0.5
         assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
         self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
-        setup_gemm_tuning()
+        if gemm_tuning not in ("table", "online", "off"):
+            raise ValueError("gemm_tuning must be 'table' (shipped TunableOp table), 'online' (also tune new shapes) or 'off'")
+        setup_gemm_tuning(tune_new_shapes=gemm_tuning == "online", use_table=gemm_tuning != "off")
 
     # ------------------------------------------------------------------------------------------
     def _pos(self, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:

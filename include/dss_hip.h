@@ -152,7 +152,7 @@ int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, int N, int D,
 
 /* The same build for features that never were fp32 on the way in - the in-memory pipeline, where the K projection hands
  * its output over through dss_kfeatures_finalize: f16 features [B, N, D] + their inverse norms [B, N] in, packed 16-bit W
- * out.  256 x 256 block tiles, panels by LDS-DMA (affinity.hip: gram_f16_dma_kernel).  Algorithmic bytes per image:
+ * out.  256 x 128 block tiles, panels by LDS-DMA (affinity.hip: gram_f16_dma_kernel).  Algorithmic bytes per image:
  * 2 N D + 4 N in, 2 * dss_affinity_elems(N) out.  D % 32 == 0.  extract/extract.py:148,191-193. */
 int dss_affinity_f16_u16(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, int D, void* stream);
 

@@ -701,53 +701,6 @@ def make_localization_golden(ref):
     print(f"[golden] localization: {len(cases)} masks; preds e.g. {[c['pred'] for c in cases[:6]]}")
 
 
-def make_semantic_golden(ref):
-    """Reference ``extract_bbox_clusters`` (extract.py:547-599; seeded MiniBatchKMeans + PCA) and
-    ``extract_semantic_segmentations`` (:602-647) on the multi-region PNGs / boxes of the `consumers` golden and seeded
-    box features."""
-    import json
-    from PIL import Image
-
-    g = np.load(GOLDEN / "consumers.npz")
-    boxes = json.loads(str(g["bboxes__default"]))
-    rng = np.random.default_rng(123)
-    centres = rng.normal(size=(4, 24)).astype(np.float32)
-    out = {}
-    with tempfile.TemporaryDirectory() as tmp:
-        sdir = Path(tmp) / "s"
-        sdir.mkdir()
-        bbox_list = []
-        for d in boxes:
-            Image.fromarray(g[f"{d['id']}__png"]).save(sdir / f"{d['id']}.png")
-            n = len(d["bboxes"])
-            feats = centres[rng.integers(0, 4, size=n)] + 0.3 * rng.normal(size=(n, 24)).astype(np.float32)
-            out[f"{d['id']}__features"] = feats.astype(np.float32)
-            bbox_list.append(dict(d, features=torch.from_numpy(feats.astype(np.float32))))
-        torch.save(bbox_list, Path(tmp) / "bf.pth")
-        for tag, kw in (("pca8_k5", dict(pca_dim=8, num_clusters=5, seed=0)), ("nopca_k3", dict(pca_dim=0, num_clusters=3, seed=4))):
-            ref.extract_bbox_clusters(bbox_features_file=str(Path(tmp) / "bf.pth"), output_file=str(Path(tmp) / f"c_{tag}.pth"), **kw)
-            res = torch.load(Path(tmp) / f"c_{tag}.pth", weights_only=False)
-            assert all("features" not in d for d in res)
-            out[f"clusters__{tag}"] = np.array(json.dumps([np.asarray(d["clusters"]).tolist() for d in res]))
-            out[f"clusters_dtype__{tag}"] = np.array(str(np.asarray(res[0]["clusters"]).dtype))
-            odir = Path(tmp) / f"sem_{tag}"
-            # the reference predates torch 2.6 (weights_only=True by default): its plain torch.load cannot read the numpy
-            # `clusters` it has just written - give that call the old default
-            real_load = torch.load
-            torch.load = lambda *a, **k: real_load(*a, **{**k, "weights_only": k.get("weights_only", False)})
-            try:
-                ref.extract_semantic_segmentations(segmentations_dir=str(sdir), bbox_clusters_file=str(Path(tmp) / f"c_{tag}.pth"),
-                                                   output_dir=str(odir))
-            finally:
-                torch.load = real_load
-            for d in res:
-                out[f"semantic__{tag}__{d['id']}"] = np.array(Image.open(odir / f"{d['id']}.png"))
-            print(f"[golden] semantic {tag}: clusters {[np.asarray(d['clusters']).tolist() for d in res]}")
-    np.savez_compressed(GOLDEN / "semantic.npz", boxes=np.array(json.dumps(boxes)),
-                        runs=np.array(json.dumps([["pca8_k5", dict(pca_dim=8, num_clusters=5, seed=0)],
-                                                  ["nopca_k3", dict(pca_dim=0, num_clusters=3, seed=4)]])), **out)
-
-
 def main():
     assert REFERENCE.is_dir(), "make_golden.py runs only where /root/reference is mounted"
     GOLDEN.mkdir(parents=True, exist_ok=True)
@@ -761,7 +714,7 @@ def main():
              "eigs": make_eig_goldens,
              "single_region": make_single_region_golden, "modes": make_mode_goldens,
              "consumers": make_consumer_goldens, "bbox_features": make_bbox_feature_golden, "color": make_color_goldens,
-             "localization": make_localization_golden, "semantic": make_semantic_golden}
+             "localization": make_localization_golden}
     assert only <= set(steps), f"unknown step(s) {only - set(steps)}; known: {sorted(steps)}"
     for name, fn in steps.items():
         if not only or name in only:

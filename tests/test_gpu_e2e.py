@@ -12,7 +12,7 @@ import dss_amd  # noqa: F401
 from dss_amd import extract, extract_utils, pipeline, synthetic
 from dss_amd.vit import DinoViT
 from oracle import spectral_ref, vit_ref
-from tests.util import build_w64, check_eigs
+from tests.util import build_w64, check_eigs, oracle_target
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
@@ -146,7 +146,7 @@ def test_end_to_end_eigenvectors_within_1e4_of_cpu_path(dtype):
         img = synthetic.synthetic_image(idx, h, w)
         _, ev, vec, info = pipeline.features_and_eigs(model, torch.from_numpy(img)[None].to(DEV), 5)
         kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
-        lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(kr, 5)
+        lam, v, ext, _ = oracle_target(kr, 5)
         assert info.item() > 0
         # eigenVALUES inherit the relative error of the half-precision ViT features (~6e-4 fp16, ~5e-3 bf16);
         # the BASELINE.json bar is on the eigenVECTORS (1e-4 cosine), which check_eigs enforces unchanged.
@@ -166,7 +166,7 @@ def test_config5_mixed_size_vitb8_k20():
     assert info.item() > 0 and tuple(vec.shape) == (1, K, (h // 8) * (w // 8))
     kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
     assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
-    lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(kr, K)
+    lam, v, ext, _ = oracle_target(kr, K)
     report = []
     check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what="config5", lam_tol=1e-3,
                d=build_w64(kr[0].numpy())[1], ext=ext, report=report)
@@ -187,7 +187,7 @@ def test_config3_vitb8_480_k15_end_to_end():
         assert info.item() > 0 and tuple(vec.shape) == (1, K, 3600) and tuple(k.shape) == (1, 3600, 768)
         kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(img))
         assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
-        lam, v, ext, draws = spectral_ref.ref_laplacian_eigs_ext(kr, K)
+        lam, v, ext, draws = oracle_target(kr, K)
         report = []
         ce = check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"config3 img{idx}",
                         lam_tol=1e-3, d=build_w64(kr[0].numpy())[1], ext=ext, report=report)
@@ -224,7 +224,7 @@ def test_config5_upper_size_range_640_vitb8_k20():
         k, ev, vec, info = pipeline.features_and_eigs(model, torch.from_numpy(img)[None].to(DEV), K)
         assert info.item() > 0 and tuple(vec.shape) == (1, K, n) and tuple(k.shape) == (1, n, 768)
         assert ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item() < 4e-3
-        lam, v, ext, draws = spectral_ref.ref_laplacian_eigs_ext(kr, K)
+        lam, v, ext, draws = oracle_target(kr, K)
         dref = build_w64(kr[0].numpy())[1]
         ev2, vec2, info2 = spectral.laplacian_eigs_from_features(kr.to(DEV), K)
         assert info2.item() > 0
@@ -267,13 +267,13 @@ def test_config5_vitb8_mixed_sizes_k20_through_the_cli(tmp_path):
         assert f["shape"] == (1, 3, h, w) and tuple(f["k"].shape) == (1, n, 768) and tuple(e["eigenvectors"].shape) == (20, n)
         kr = vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(synthetic.synthetic_image(idx, h, w)))
         assert ((f["k"] - kr).norm() / kr.norm()).item() < 4e-3
-        lam, v, ext, draws = spectral_ref.ref_laplacian_eigs_ext(kr, 20)
+        lam, v, ext, draws = oracle_target(kr, 20)
         dref = build_w64(kr[0].numpy())[1]
         ev2, vec2, info2 = spectral.laplacian_eigs_from_features(kr.to(DEV), 20)
         assert info2.item() > 0
         check_eigs(vec2[0].cpu().numpy(), ev2[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"config5 eig-stage {name}",
                    d=dref, ext=ext)
-        lam_h, v_h, ext_h, _ = spectral_ref.ref_laplacian_eigs_ext(f["k"], 20)
+        lam_h, v_h, ext_h, _ = oracle_target(f["k"], 20)
         check_eigs(e["eigenvectors"].numpy(), e["eigenvalues"].numpy(), v_h.numpy(), lam_h.numpy(),
                    what=f"config5 eigen file vs eigsh on its own features {name}", d=build_w64(f["k"][0].numpy())[1], ext=ext_h)
         report = []
@@ -387,7 +387,7 @@ def test_cli_two_stage_roundtrip_and_resume(tmp_path, capsys):
         assert sorted(ed) == ["eigenvalues", "eigenvectors"]
         assert ed["eigenvalues"].dtype == torch.float32 and ed["eigenvalues"].shape == (5,)
         assert ed["eigenvectors"].dtype == torch.float32 and ed["eigenvectors"].shape == (5, 48)
-        lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(fd["k"], 5)  # oracle on the SAVED features: eigen-stage parity
+        lam, v, ext, _ = oracle_target(fd["k"], 5)  # oracle on the SAVED features: eigen-stage parity
         check_eigs(ed["eigenvectors"].numpy(), ed["eigenvalues"].numpy(), v.numpy(), lam.numpy(), what=fn,
                    d=build_w64(fd["k"][0].numpy())[1], ext=ext)
     # resume: nothing is recomputed, files untouched
@@ -472,7 +472,7 @@ def test_extract_eigs_on_the_reference_written_feature_file(tmp_path, golden_dir
     feat.mkdir()
     shutil.copy(golden_dir / "ref_feature_file.pth", feat / "renamed.pth")
     k = torch.load(golden_dir / "ref_feature_file.pth", map_location="cpu", weights_only=True)["k"]
-    lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(k.contiguous(), 3)
+    lam, v, ext, _ = oracle_target(k.contiguous(), 3)
     for tag, procs in (("threads", "0"), ("procs", "2")):
         monkeypatch.setenv("DSS_IO_PROCESSES", procs)
         extract.main(["extract_eigs", "--images_root", "", "--features_dir", str(feat), "--output_dir",
@@ -523,6 +523,81 @@ def test_cli_two_ranks_shard_round_robin(tmp_path):
                    e1["eigenvalues"].numpy(), what=n)
 
 
+_RCCL_WORLD1 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import dss_amd
+from dss_amd import distributed
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dev = distributed.local_device()
+dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(1)
+ids = torch.tensor([5, 2, 2 ** 41 + 3, 0], device=dev)
+ev, vec = torch.randn(4, 3, generator=g).to(dev), torch.randn(4, 3, 50, generator=g).to(dev)
+meta, flat = distributed.pack_records(ids, ev, vec)
+m2, p2 = distributed.gather_records_to_root(meta, flat)          # sizes round = an RCCL gather on device tensors
+assert m2.is_cuda and p2.is_cuda and m2[:, 0].tolist() == sorted(ids.tolist())
+got = {i: (a, b) for i, a, b in distributed.unpack_records(m2.cpu(), p2.cpu())}
+for j, i in enumerate(ids.tolist()):
+    assert torch.equal(got[i][0], ev[j].cpu()) and torch.equal(got[i][1], vec[j].cpu())
+# the payload round's primitive (batch_isend_irecv of device tensors), rank 0 to itself: RCCL send / recv inside one group
+back_m, back_p = torch.empty_like(meta).view(-1), torch.empty_like(flat)
+ops = [dist.P2POp(dist.isend, meta.reshape(-1), 0), dist.P2POp(dist.isend, flat, 0),
+       dist.P2POp(dist.irecv, back_m, 0), dist.P2POp(dist.irecv, back_p, 0)]
+for w in dist.batch_isend_irecv(ops):
+    w.wait()
+torch.cuda.synchronize()
+assert torch.equal(back_m.view_as(meta), meta) and torch.equal(back_p, flat)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+"""
+
+
+def test_gather_over_rccl_with_one_rank(tmp_path):
+    """The `nccl` (= RCCL) branch of distributed.gather_records_to_root on DEVICE tensors, as far as ONE GPU can take it: a
+    one-rank RCCL process group, the sizes round through it, and the payload round's primitive (batch_isend_irecv of device
+    tensors) from rank 0 to itself.  (Two ranks on one device are refused by RCCL; the 2-GPU test below runs where it can.)"""
+    import subprocess
+    import sys
+
+    repo = Path(__file__).resolve().parents[1]
+    script = tmp_path / "rccl_world1.py"
+    script.write_text(_RCCL_WORLD1)
+    r = subprocess.run([sys.executable, str(script), str(repo), "29541"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_two_gpus_over_rccl():
+    """`python bench.py --gpus 2` with the nccl backend: two ranks, two devices, ordered unique ids in the one gathered
+    payload (asserted inside bench.py), `ranks_seen == 2`, and per-image results equal to a one-rank run of the same items.
+    Needs two GPUs: on a one-GPU box this test SKIPS and says so (RCCL refuses two ranks on one device) - the RCCL path
+    has then only run as far as test_gather_over_rccl_with_one_rank takes it."""
+    import json
+    import subprocess
+    import sys
+
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip(f"SKIPPED LOUDLY: {ndev} GPU visible - `bench.py --gpus 2` over nccl (RCCL) needs two devices; the "
+                    f"multi-rank collection has run over gloo (test_cli_two_ranks_shard_round_robin, tests/test_distributed_cpu.py) "
+                    f"and over RCCL with one rank (test_gather_over_rccl_with_one_rank) only")
+    repo = Path(__file__).resolve().parents[1]
+    common = ["--steps", "2", "--warmup", "1", "--min-warmup-seconds", "0", "--cpu-images", "0", "--companion-steps", "0",
+              "--dino-like-steps", "0", "--batch", "64", "--vit-batch", "32", "--size", "224", "--distinct", "64"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DSS_DIST_BACKEND", None)
+    r2 = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", *common], capture_output=True, text=True,
+                        timeout=1200, env=env)
+    assert r2.returncode == 0, r2.stderr[-4000:]
+    d2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["ranks_seen"] == 2 and d2["backend"] == "nccl"
+    assert len({dev for _, dev in d2["rank_devices"]}) == 2
+    assert d2["config"]["images_total"] == 2 * 2 * 64 and d2["unconverged_images"] == 0
+
+
 def test_cli_other_which_matrix_branches(tmp_path):
     """extract_eigs --which_matrix affinity / affinity_svd and --lapnorm False write the reference's schemas."""
     feats = synthetic.synthetic_features("blobs", 196, 384, 102, (14, 14))
@@ -563,7 +638,7 @@ def test_fp16_path_survives_dino_like_outlier_activations(name, h, w, K):
     kr = vit_ref.ref_extract_k(ref, x)
     rel = ((k[0].cpu() - kr[0]).norm() / kr[0].norm()).item()
     assert rel < 6e-3, rel
-    lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(kr, K)
+    lam, v, ext, _ = oracle_target(kr, K)
     report = []
     ce = check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"outliers {name}",
                     lam_tol=2e-3, d=build_w64(kr[0].numpy())[1], ext=ext, report=report)

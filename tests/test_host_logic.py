@@ -145,22 +145,6 @@ def test_synthetic_inputs_are_portable():
     assert sd["patch_embed.proj.weight"].shape == (768, 3, 8, 8)
 
 
-def test_single_region_segmentation_matches_reference_golden(tmp_path, golden_dir):
-    """the eigen files' immediate consumer, against the reference's own output."""
-    from PIL import Image
-
-    g = np.load(golden_dir / "single_region.npz")
-    shape, patch, vec = tuple(int(v) for v in g["shape"]), int(g["patch"]), g["eigenvectors"]
-    (tmp_path / "f").mkdir(), (tmp_path / "e").mkdir()
-    n = vec.shape[1]
-    torch.save({"k": torch.zeros(1, n, 8), "indices": torch.tensor(0), "file": "seg_x.jpg", "id": "seg_x",
-                "model_name": "dino_vits16", "patch_size": patch, "shape": shape}, tmp_path / "f" / "seg_x.pth")
-    torch.save({"eigenvalues": torch.zeros(3), "eigenvectors": torch.from_numpy(vec)}, tmp_path / "e" / "seg_x.pth")
-    extract.extract_single_region_segmentations(str(tmp_path / "f"), str(tmp_path / "e"), str(tmp_path / "o"))
-    png = np.array(Image.open(tmp_path / "o" / "seg_x.png"))
-    assert png.dtype == g["png"].dtype and np.array_equal(png, g["png"])
-
-
 def test_wave_filling_batch_picks_whole_waves_of_workgroups():
     """vit.wave_filling_batch: images per ViT forward such that ceil(b * tokens / 512) workgroups of the K-resident
     Linear kernel fill whole waves of the CUs (pure arithmetic; no GPU)."""
