@@ -44,12 +44,20 @@
 #define DSS_WAVE_SYNC() ((void)0)
 #define DSS_RSQRT64(x) (1.0 / sqrt(x))
 #define DSS_SETPRIO(p) ((void)0)
+#define DSS_UNIFORM(p) ((void)0)
+#define DSS_F64C(x) ((double)(float)(x))
+#define DSS_FRESH_F32(x) (x)
 #else
 #define DSS_DEV __device__ __forceinline__
 #define DSS_HD __host__ __device__
-#define DSS_TID ((int)threadIdx.x)
+// Thread / lane ids come through an opaque asm at every use: left visible, hipcc hoists every value derived from them
+// (element offsets, LDS addresses, predicates of a dozen phases) out of the restart loop and keeps them live through the
+// whole solver - 81 spilled VGPRs and a scratch round trip at every phase boundary (round 3); recomputing them costs a
+// v_mov and an add per phase.
+__device__ __forceinline__ int dss_fresh_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#define DSS_TID (dss_fresh_tid())
 #define DSS_NT ((int)blockDim.x)
-#define DSS_LANE ((int)(threadIdx.x & 63))
+#define DSS_LANE (dss_fresh_tid() & 63)
 #define DSS_WAVE (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))   /* wave-uniform: tile indices and their addresses stay scalar */
 #define DSS_NWAVES ((int)(blockDim.x >> 6))
 #define DSS_LANES 64
@@ -63,6 +71,20 @@
                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define DSS_RSQRT64(x) ::dss::rsqrt64(x)
 #define DSS_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+// a workgroup-uniform pointer / integer goes (back) into scalar registers here: hipcc loses the uniformity of pointers that
+// are swapped inside the restart loop and then carries them - and everything derived from them - per lane
+template <class T> __device__ __forceinline__ T* dss_uniform_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+#define DSS_UNIFORM(p) ((p) = dss_uniform_ptr(p))
+// An fp64 literal that is not an inline constant occupies a register PAIR, which hipcc hoists out of every loop and keeps
+// for the whole kernel (and then spills).  Thresholds and 1.5 are exact enough as an f32 literal widened where it is used.
+__device__ __forceinline__ double dss_f64c(float c) { asm volatile("" : "+v"(c)); return (double)c; }
+#define DSS_F64C(x) dss_f64c((float)(x))
+__device__ __forceinline__ float dss_fresh_f32(float c) { asm volatile("" : "+v"(c)); return c; }
+#define DSS_FRESH_F32(x) dss_fresh_f32(x)
 #endif
 
 // Lab build (-DDSS_EIGS_TIMELINE, scripts/debug/eigs_lab.py): thread 0 of every workgroup adds the shader-clock cycles
@@ -173,8 +195,9 @@ struct EigsSmall {  // lives in LDS at off_small (<= 6144 B)
 // 1 / sqrt(x) for x in [1, 2] to fp64 rounding: v_rsq_f64 seed + two Newton steps (no IEEE divide / sqrt expansion)
 DSS_DEV double rsqrt64(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
+  const double c15 = DSS_F64C(1.5f);
+  y = y * (c15 - 0.5 * x * y * y);
+  y = y * (c15 - 0.5 * x * y * y);
   return y;
 }
 #endif
@@ -633,8 +656,9 @@ DSS_DEV void jacobi_eig(double* A, double* Vr, int m, EigsSmall* sm, bool by_mag
         if (q < m) {   // q == m: the dummy index of an odd m - identity
           const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q], apq = A[(size_t)q * m + p];
           const double a2 = apq * apq, d2 = fabs(app * aqq);
-          if (a2 > 1e-34 + 1e-20 * d2) sm->big = 1;  // |a_pq| > 1e-10 sqrt|a_pp a_qq|; benign race: every writer stores 1
-          if (a2 > 1e-34 + 1e-30 * d2) {             // |a_pq| > 1e-15 sqrt|a_pp a_qq|
+          const double tiny = DSS_F64C(1e-34f);
+          if (a2 > tiny + DSS_F64C(1e-20f) * d2) sm->big = 1;  // |a_pq| > 1e-10 sqrt|a_pp a_qq|; benign race: every writer stores 1
+          if (a2 > tiny + DSS_F64C(1e-30f) * d2) {             // |a_pq| > 1e-15 sqrt|a_pp a_qq|
             const float h = (float)(0.5 * (aqq - app)), bq = (float)apq;
             const float tf = bq / (fabsf(h) + sqrtf(h * h + bq * bq));   // tan of the smaller rotation angle
             const double t = (double)(h < 0.f ? -tf : tf);
@@ -730,15 +754,16 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
   int nbad = 0;
   double worst = 0.;
   for (int i = 0; i < K; ++i) {
-    if (i >= m) { ++nbad; worst = 1e30; continue; }
+    if (i >= m) { ++nbad; worst = DSS_F64C(1e30f); continue; }
     const int c = sm->perm[i];
     const double res = fabs(beta_last * Vr[(size_t)c * m + (m - 1)]);
     const double th = fabs(sm->theta[c]);
-    const double bar = (double)tol * (th > 1e-3 * tmax ? th : 1e-3 * tmax);
+    const double floor_ = DSS_F64C(1e-3f) * tmax;
+    const double bar = (double)DSS_FRESH_F32(tol) * (th > floor_ ? th : floor_);
     if (res > bar) ++nbad;
     if (res > worst * bar) worst = res / bar;
   }
-  if (worst_ratio) *worst_ratio = (float)(worst < 1e30 ? worst : 1e30);
+  if (worst_ratio) *worst_ratio = (float)(worst < DSS_F64C(1e30f) ? worst : DSS_F64C(1e30f));
   return nbad;
 }
 
@@ -758,8 +783,8 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
   double* Vr = reinterpret_cast<double*>(lds + L.off_V);
   EigsSmall* sm = reinterpret_cast<EigsSmall*>(lds + L.off_small);
   const int ldv = ld;
-  float* Va = gws;
-  float* Vb = gws + (size_t)(mmax + 1) * ldv;
+  float* Va = gws;                                   // the basis in use; the other of the two buffers (a restart's target) is
+                                                     // derived where it is needed, not carried through the solver
   float* dis = gws + (size_t)2 * (mmax + 1) * ldv;
   int passes = 0;
   DSS_ETL_DECL
@@ -799,6 +824,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
     bool breakdown = false, early = false;
     int next_check = 0;
     for (int j = l; j < mmax; ++j) {
+      DSS_UNIFORM(Va); DSS_UNIFORM(dis);
       const float* vj = Va + (size_t)j * ldv;
       // Convergence check of the CURRENT state (j basis vectors, T_j, beta_last = beta_{j-1}) by the last wave, beside
       // the W stream of step j (the Jacobi sweeps are latency-bound and need no bandwidth).  A converged image is
@@ -869,6 +895,8 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
     converged = (nbad == 0);
     if (converged || breakdown || restart >= P.max_restarts) break;
     // ---- thick restart: keep the best `keep` Ritz vectors -----------------------------------------------
+    float* Vb = Va == gws ? gws + (size_t)(mmax + 1) * ldv : gws;
+    DSS_UNIFORM(Va); DSS_UNIFORM(Vb);
     int keep = P.keep < m - 2 ? P.keep : m - 2;
     if (keep < K) keep = K < m - 1 ? K : m - 1;
     DSS_SYNC();
@@ -901,7 +929,8 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
       sm->alpha[i] = sm->theta[c];
       sm->arrow[i] = beta_last * Vr[(size_t)c * m + (m - 1)];
     }
-    { float* t = Va; Va = Vb; Vb = t; }
+    Va = Vb;
+    DSS_UNIFORM(Va);
     l = keep;
     DSS_SYNC();
     DSS_ETL_MARK(5)
@@ -909,6 +938,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
 
   // ---- Ritz vectors -> generalized eigenvectors v = D^-1/2 u, sign rule, eigenvalues ----------------------
   DSS_SYNC();
+  DSS_UNIFORM(Va); DSS_UNIFORM(dis); DSS_UNIFORM(eigenvectors);
   const float vscale = sqrtf(WElem<WE>::scale);
   float* Zf = reinterpret_cast<float*>(A);
   for (int idx = DSS_TID; idx < m * K; idx += DSS_NT) {

@@ -201,6 +201,9 @@ def test_config3_vitb8_480_k15_end_to_end():
 
 
 @pytest.mark.timeout(2400)
+# ONE image, K = 20 at N = 6400: eigenvalues 9..46 lie within 1e-4 of each other and every fp32 ARPACK draw of the
+# reference is > 1e-5 from fp64 on the isolated vectors (draws = -4): this test's target is the fp64 substitute, by design
+@pytest.mark.oracle_substitute(max_share=1.0)
 def test_config5_upper_size_range_640_vitb8_k20():
     """BASELINE config 5's UPPER size range through the whole path: dino_vitb8 at 640 x 640 (T = 6401 tokens, N = 6400
     patches - the largest shape of the config) with K = 20, and an odd size above 480 px (523 x 637 -> 65 x 79 patches,
