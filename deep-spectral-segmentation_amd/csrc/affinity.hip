@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __r
 static constexpr int G3R = 256;      // block tile rows
 static constexpr int G3C = 128;      // block tile columns
 static constexpr int G3K = 32;       // feature columns per stage (64-byte rows)
+static constexpr long G3PASS_BYTES = 2883584;   // 2.75 MB of column panels per group (+ ~1.2 MB of row panels in flight < 4 MB L2)
 
 __global__ __launch_bounds__(512, 4) void gram_f16_dma_kernel(const f16* __restrict__ feats, const float* __restrict__ rnorm,
                                                               uint16_t* __restrict__ W, int N, int D, int ldw,
@@ -560,9 +561,30 @@ __global__ __launch_bounds__(512, 4) void gram_f16_dma_kernel(const f16* __restr
       rem = r % nblk;
     }
   }
-  int bi = 0, cj;                                        // row block bi holds column blocks 2 bi .. ncj - 1
-  while (rem >= ncj - 2 * bi) { rem -= ncj - 2 * bi; ++bi; }
-  cj = 2 * bi + rem;
+  // Block order inside an image.  Row block bi (256 rows) holds column blocks 2 bi .. ncj - 1 (128 columns).  The blocks of an
+  // image run on ONE XCD, ~64 at a time: in plain row-major order those touch every column panel of the image again for
+  // every row block, and once an image's f16 features outgrow the XCD's 4 MB L2 (dino_vitb8 at 480 x 480: 5.5 MB) the column
+  // panels come back through the fabric each time - 19.8 GB moved for 9.5 GB algorithmic per 512 images (round 3).  So the
+  // columns are cut into `npass` groups of <= ~2.75 MB of panels, the row blocks of the upper triangle run per group, and a
+  // group's column panels stay L2-resident under all of them (row panels are read once per group they meet).
+  const int npass = (int)(((long)N * D * 2 + G3PASS_BYTES - 1) / G3PASS_BYTES);
+  int bi = 0, cj = 0;
+  if (npass <= 1) {
+    while (rem >= ncj - 2 * bi) { rem -= ncj - 2 * bi; ++bi; }
+    cj = 2 * bi + rem;
+  } else {
+    const int per = (ncj + npass - 1) / npass;             // column blocks per group
+    for (int c0 = 0; c0 < ncj; c0 += per) {
+      const int c1 = min(c0 + per, ncj);
+      bool found = false;
+      for (bi = 0; 2 * bi < c1; ++bi) {
+        const int lo = max(2 * bi, c0), cnt = c1 - lo;
+        if (rem < cnt) { cj = lo + rem; found = true; break; }
+        rem -= cnt;
+      }
+      if (found) break;
+    }
+  }
   const int I0 = bi * G3R, J0 = cj * G3C;
   const f16* F = feats + (long)img * N * D;
   const float* R = rnorm + (long)img * N;

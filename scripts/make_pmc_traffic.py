@@ -12,8 +12,11 @@ import csv
 import json
 import sys
 
-KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name
-    "linear_kres": "linear_kres_kernel",
+KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name (or a predicate on it)
+    # one template, two bench keys: the last template argument is LNM (0 = plain Linear, 1 / 2 = LayerNorm prologue)
+    # (mangled names: ...linear_kres_kernelIDF16_Lb1ELi24ELi2ELi4ELi<LNM>EEEv...)
+    "linear_kres": lambda n: "linear_kres_kernel" in n and "ELi0EEEv" in n,
+    "lnlinear": lambda n: "linear_kres_kernel" in n and "EEEv" in n and "ELi0EEEv" not in n,
     "attention": "attn_fwd",
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_",
@@ -41,7 +44,7 @@ def main():
     cfg = json.loads(open(bench_json).read().strip().splitlines()[-1])["config"]
     kernels = {}
     for key, sub in KEYS.items():
-        names = [n for n in fr if sub in n and n in wr]
+        names = [n for n in fr if (sub(n) if callable(sub) else sub in n) and n in wr]
         if not names:
             continue
         # several template instantiations (e.g. GELU / no GELU) share a key: dispatch-weighted average
