@@ -258,21 +258,32 @@ def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fus
     stream.  Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
     counts = chunk_counts(cnt, vit_batch)
     f16 = mode == "fused" and w_dtype == "u16"
-    parts = []
+    parts, bufs, s0 = [], None, 0
     for j, n in enumerate(counts):
         if j + 1 < len(counts):
             feeder.prefetch(c0 + j + 1, counts[j + 1])
         elif nxt is not None:
             feeder.prefetch(*nxt)
         imgs = feeder.get(c0 + j, n)
-        parts.append(model.extract_k_f16(imgs) if f16 else (model.extract_k(imgs),))
+        if f16:
+            # the forwards' hand-over kernels write straight into the step's three buffers (fp32 features, f16 copy,
+            # inverse norms): no concatenation pass over 2.8 + 1.4 GB in front of the affinity build
+            if bufs is None:
+                npatch, dim = (imgs.shape[1] // model.patch_size) * (imgs.shape[2] // model.patch_size), model.embed_dim
+                bufs = (torch.empty((cnt, npatch, dim), dtype=torch.float32, device=imgs.device),
+                        torch.empty((cnt, npatch, dim), dtype=torch.float16, device=imgs.device),
+                        torch.empty((cnt, npatch), dtype=torch.float32, device=imgs.device))
+            model.extract_k_f16(imgs, out=tuple(b_[s0:s0 + n] for b_ in bufs))
+            s0 += n
+        else:
+            parts.append(model.extract_k(imgs))
         feeder.release(c0 + j)
-    cat = lambda i: torch.cat([p_[i] for p_ in parts]) if len(parts) > 1 else parts[0][i]
     if f16:
-        out = spectral.laplacian_eigs_from_features(cat(0), K, strict=False, retry=False, w_dtype=w_dtype,
-                                                    affinity_mode=mode, feats16=cat(1), rnorm=cat(2))
+        out = spectral.laplacian_eigs_from_features(bufs[0], K, strict=False, retry=False, w_dtype=w_dtype,
+                                                    affinity_mode=mode, feats16=bufs[1], rnorm=bufs[2])
     else:
-        out = spectral.laplacian_eigs_from_features(cat(0), K, strict=False, retry=False, w_dtype=w_dtype, affinity_mode=mode)
+        k = torch.cat(parts) if len(parts) > 1 else parts[0]
+        out = spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype, affinity_mode=mode)
     return (*out, len(counts))
 
 

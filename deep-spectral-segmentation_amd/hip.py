@@ -406,14 +406,21 @@ def affinity_f16_u16(feats16: torch.Tensor, rnorm: torch.Tensor) -> torch.Tensor
     return w
 
 
-def kfeatures_finalize(kproj: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-12):
+def kfeatures_finalize(kproj: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-12, out=None):
     """Raw K-projection output ``[B, T, D]`` f32 (+ ``bias [D]``) -> ``(k32 [B, T-1, D] f32, k16 the same in f16,
-    rnorm [B, T-1])`` in one pass (``dss_kfeatures_finalize``: bias add, CLS drop, f16 copy, inverse norms)."""
+    rnorm [B, T-1])`` in one pass (``dss_kfeatures_finalize``: bias add, CLS drop, f16 copy, inverse norms).  ``out``: the
+    three destinations (contiguous, e.g. ``[s:s+B]`` slices of a step's buffers: several ViT forwards then fill ONE batch
+    for the affinity build without a concatenation pass)."""
     assert kproj.dtype == torch.float32 and kproj.dim() == 3
     b, t, d = kproj.shape
-    k32 = torch.empty((b, t - 1, d), dtype=torch.float32, device=kproj.device)
-    k16 = torch.empty((b, t - 1, d), dtype=torch.float16, device=kproj.device)
-    rn = torch.empty((b, t - 1), dtype=torch.float32, device=kproj.device)
+    if out is not None:
+        k32, k16, rn = out
+        assert tuple(k32.shape) == tuple(k16.shape) == (b, t - 1, d) and tuple(rn.shape) == (b, t - 1)
+        assert k32.dtype == torch.float32 and k16.dtype == torch.float16 and rn.dtype == torch.float32
+    else:
+        k32 = torch.empty((b, t - 1, d), dtype=torch.float32, device=kproj.device)
+        k16 = torch.empty((b, t - 1, d), dtype=torch.float16, device=kproj.device)
+        rn = torch.empty((b, t - 1), dtype=torch.float32, device=kproj.device)
     with _timed("kfeatures_finalize", b=b, t=t, d=d):
         _check(load_library().dss_kfeatures_finalize(_dev(kproj, "kproj"), 0 if bias is None else _dev(bias, "bias"),
                                                      _dev(k32, "k32"), _dev(k16, "k16"), _dev(rn, "rnorm"), b, t, d,

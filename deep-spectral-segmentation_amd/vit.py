@@ -244,15 +244,15 @@ class DinoViT:
         return F.layer_norm(cls, (self.embed_dim,), self.norm_w, self.norm_b, LN_EPS)
 
     @torch.no_grad()
-    def extract_k_f16(self, img_u8: torch.Tensor, which_block: int = -1):
+    def extract_k_f16(self, img_u8: torch.Tensor, which_block: int = -1, out=None):
         """``extract_k`` for a consumer that stays on the GPU (``pipeline.features_and_eigs``): returns
         ``(k [B, N, D] fp32, k16 the same in f16, rnorm [B, N] = 1 / |k16 row|)`` - the hand-over of
         ``hip.kfeatures_finalize`` (bias add, CLS drop, f16 copy and inverse norms in one pass) that the f16-input
         affinity build (``hip.affinity_f16_u16``) starts from."""
-        return self.extract_k(img_u8, which_block, _finalize=True)
+        return self.extract_k(img_u8, which_block, _finalize=True, _out=out)
 
     @torch.no_grad()
-    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1, _finalize: bool = False) -> torch.Tensor:
+    def extract_k(self, img_u8: torch.Tensor, which_block: int = -1, _finalize: bool = False, _out=None) -> torch.Tensor:
         """``img_u8``: u8 ``[B, H, W, 3]`` RGB on the GPU (uncropped).  Returns the hooked K features
         ``[B, N, D]`` fp32, ``N = (H//P)*(W//P)``, rows in row-major patch order, CLS removed."""
         assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
@@ -276,11 +276,11 @@ class DinoViT:
             with hip._timed("library_gemm", m=b * t, n=d, k=d, what="k_proj"):
                 k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
             if _finalize and n > 0:
-                return hip.kfeatures_finalize(k, blk["k_b32"])
+                return hip.kfeatures_finalize(k, blk["k_b32"], out=_out)
             k += blk["k_b32"]
         k = k[:, 1:, :].contiguous()
         if _finalize:   # the all-fp32 K projection (or a degenerate grid): same hand-over, no extra bias
-            return hip.kfeatures_finalize(torch.cat((k[:, :1], k), dim=1), None)
+            return hip.kfeatures_finalize(torch.cat((k[:, :1], k), dim=1), None, out=_out)
         return k
 
 

@@ -44,5 +44,35 @@ int main(int argc, char** argv) {
            100.0 * r[3] / wg / tot, (double)r[0] / wg, (double)r[1] / wg / (c.N / 32), (double)r[2] / wg / (c.N / 32), (double)r[3] / wg / (c.N / 32),
            (double)r[5] / wg / 100.0, tot / ((double)r[5] / wg / 100.0), wg / reps, (wg / reps) * ((double)r[5] / wg / 100.0) / (512.0 * ms / reps * 1e3));
   }
+  // ---- round 4: the LayerNorm-prologue variants (dss_lnlinear_k384): x f32 (+ residual f16, row-major) -> same outputs ----
+  float *X, *AUX;
+  if (hipMalloc(&X, (size_t)M * K * 4) != hipSuccess || hipMalloc(&AUX, 1536 * 2 * 4) != hipSuccess) return 1;
+  {
+    std::vector<float> hx((size_t)M * K), haux(1536 * 2);
+    for (auto& v : hx) v = rnd() * 3.f;
+    for (auto& v : haux) v = rnd();
+    (void)hipMemcpy(X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(AUX, haux.data(), haux.size() * 4, hipMemcpyHostToDevice);
+  }
+  struct LCase { const char* name; int N, gelu, planar, res; } lcases[] = {{"LN+qkv (no residual)", 1152, 0, 1, 0}, {"res+LN+qkv", 1152, 0, 1, 1},
+                                                                          {"LN+fc1+gelu (no res)", 1536, 1, 0, 0}, {"res+LN+fc1+gelu", 1536, 1, 0, 1}};
+  for (auto& c : lcases) {
+    for (int w = 0; w < 3; ++w) dss_lnlinear_k384(X, c.res ? A : nullptr, DSS_ROW_MAJOR, 1e-6f, W, AUX, C, M, c.N, c.gelu, c.planar, DSS_F16, nullptr);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dss_lin_tl), z, sizeof(z));
+    (void)hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) dss_lnlinear_k384(X, c.res ? A : nullptr, DSS_ROW_MAJOR, 1e-6f, W, AUX, C, M, c.N, c.gelu, c.planar, DSS_F16, nullptr);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(dss_lin_tl), sizeof(r));
+    const double wg = (double)r[4], tot = (double)(r[0] + r[1] + r[2] + r[3]) / wg;
+    const double life_us = (double)r[5] / wg / 100.0;
+    printf("%-22s N=%4d: %7.1f us; per workgroup %8.0f cycles: LN prologue %5.1f %% (%.0f cycles = %.1f us), MFMA phases %5.1f %%, epilogues %5.1f %%, "
+           "wait+barrier %5.1f %%; workgroup lifetime %.1f us -> %.0f MHz; slot occupancy %.2f\n", c.name, c.N, ms / reps * 1e3, tot,
+           100.0 * r[0] / wg / tot, (double)r[0] / wg, (double)r[0] / wg / (tot / life_us), 100.0 * r[1] / wg / tot, 100.0 * r[2] / wg / tot, 100.0 * r[3] / wg / tot,
+           life_us, tot / life_us, (wg / reps) * life_us / (512.0 * ms / reps * 1e3));
+  }
   return 0;
 }
