@@ -70,9 +70,13 @@ class HipLibraryError(RuntimeError):
 
 _lib: Optional[ctypes.CDLL] = None
 
-# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  When
-# ``TIMERS`` is a dict, every wrapper appends (start_event, end_event, meta) to TIMERS[name].
+# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  When ``TIMERS`` is a dict,
+# the wrappers append (start_event, end_event, meta) to TIMERS[name] - for every ``TIMER_SAMPLE``-th launch of a kernel name
+# (an event pair is two extra packets in the in-order queue: ~10 us of serialisation per launch on MI355X, which at 1100
+# launches per step is not a measurement any more but a load) - and count every launch in TIMERS["_launches"][name].
 TIMERS: Optional[dict] = None
+TIMER_SAMPLE = 1
+TIMER_ALWAYS = ("laplacian_eigs", "affinity", "kfeatures_finalize", "layernorm")   # a handful of launches per step: all timed
 
 
 class _timed:
@@ -83,14 +87,20 @@ class _timed:
         self.name, self.meta = name, meta
 
     def __enter__(self):
+        self.on = False
         if TIMERS is not None:
+            counts = TIMERS.setdefault("_launches", {})
+            n = counts.get(self.name, 0)
+            counts[self.name] = n + 1
+            self.on = TIMER_SAMPLE <= 1 or self.name in TIMER_ALWAYS or n % TIMER_SAMPLE == 0
+        if self.on:
             self.start = torch.cuda.Event(enable_timing=True)
             self.end = torch.cuda.Event(enable_timing=True)
             self.start.record()
         return self
 
     def __exit__(self, *exc):
-        if TIMERS is not None:
+        if self.on:
             self.end.record()
             TIMERS.setdefault(self.name, []).append((self.start, self.end, self.meta))
         return False

@@ -8,7 +8,9 @@ rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> 
 bench_summary() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print({k: d.get(k) for k in ('value', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_in_loop_ms_per_step')})
+print({k: d.get(k) for k in ('value', 'ms_per_step', 'host_enqueue_ms_per_step', 'host_in_loop_ms_per_step')}, 'images/step', d['config']['images_per_step'], 'vit_batch', d['config']['vit_batch'])
+tot = sum(v.get('total_ms', 0) for v in d['kernels'].values()) / d['steps']
+print('kernel ms/step', round(tot, 1), 'other', round(d['ms_per_step'] - tot, 1), 'us/img', round(1e3 * d['ms_per_step'] / d['config']['images_per_step'], 2))
 for k, v in d['kernels'].items(): print(k, v.get('launches'), v.get('avg_ms'), v.get('frac'), v.get('passes_per_image', ''))
 "; }
 for STAGE in "$@"; do
@@ -24,6 +26,9 @@ for STAGE in "$@"; do
     tests_all) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -60 gpurun_out/pytest_gpu.log;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -4 gpurun_out/smoke.log;;
     bench_quick) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS:-} 2> gpurun_out/bench_quick.err | tee gpurun_out/bench_quick.json | bench_summary; tail -2 gpurun_out/bench_quick.err;;
+    bench_sweep)   # SWEEP="args1|args2|...": one quick bench per entry
+      IFS='|' read -ra SW <<< "${SWEEP:-}"
+      for i in "${!SW[@]}"; do echo "--- sweep $i: ${SW[$i]}"; timeout 400 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${SW[$i]} 2> gpurun_out/bench_sweep$i.err | tee gpurun_out/bench_sweep$i.json | bench_summary | head -3; done;;
     bench_quick2) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS2:-} 2> gpurun_out/bench_quick2.err | tee gpurun_out/bench_quick2.json | bench_summary; tail -2 gpurun_out/bench_quick2.err;;
     bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
     bench_c3) timeout 900 python bench.py --model dino_vitb8 --K 15 --batch 512 --vit-batch 16 --cpu-images 2 --parity-images 2 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; echo "bench_c3 exit: $?"; tail -2 gpurun_out/bench_c3.err; cut -c1-600 gpurun_out/bench_c3.json;;
