@@ -251,9 +251,10 @@ def page_lock(t: torch.Tensor, how: str = "malloc") -> torch.Tensor:
 
 
 def chunk_counts(cnt: int, vit_batch: int):
-    """Images per ViT forward of a step of ``cnt`` images: as few forwards as ``vit_batch`` allows, of (nearly) equal size
-    (a 1250-image shard with 1160-image forwards is 2 x 625, not 1160 + 90)."""
-    n = max(1, -(-cnt // vit_batch))
+    """Images per ViT forward of a step of ``cnt`` images: forwards of at most ``vit_batch`` images and (nearly) equal size,
+    and at least four of them while they stay above 256 images - the copy of forward j + 1 runs under forward j, so a step
+    that is ONE forward (a 1250-image shard of the 8-GPU run) would wait for all of its bytes before computing anything."""
+    n = max(1, -(-cnt // vit_batch), min(4, cnt // 256))
     per, extra = divmod(cnt, n)
     return [per + (1 if i < extra else 0) for i in range(n)]
 
