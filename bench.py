@@ -51,11 +51,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0,
-                    help="images per step per GPU (0 = 1..4 ViT forwards, whichever fills whole rounds of eigensolver "
-                         "workgroups best)")
+                    help="images per step per GPU (0 = 4..8 ViT forwards, whichever fills whole rounds of eigensolver "
+                         "workgroups best: 4 x 1018 = 4072 at the headline config)")
     ap.add_argument("--vit-batch", type=int, default=0,
                     help="images per ViT forward (0 = ~1 M token rows, sized so the token matrix fills whole waves of "
-                         "workgroups: vit.wave_filling_batch; ~1160 for dino_vits16 at 480x480)")
+                         "workgroups: vit.wave_filling_batch; 1018 for dino_vits16 at 480x480)")
     ap.add_argument("--dataset", type=int, default=0,
                     help="strong scaling: a fixed set of this many images sharded round-robin over the ranks "
                          "(BASELINE.json configs[3]: 10000); --steps is then derived from the shard")
@@ -506,16 +506,16 @@ def main():
     if a.vit_batch <= 0:
         from dss_amd.vit import wave_filling_batch
         rows = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
-        # ~1 M token rows per forward (1160 images at the headline config): measured round 4 on one box, images/s with
+        # ~0.9 M token rows per forward (1018 images at the headline config): measured round 4 on one box, images/s with
         # 290 / 435 / 580 / 1160 images per forward = 12 213 / 12 430 / 12 635 / 12 754 - per-launch tails and the ~7 us between
         # launches are paid per forward, HBM (288 GB) is nowhere near a limit (a forward's activations: < 15 GB)
-        target = max(8, round(1160 * 901 / (n_patches + 1)))
+        target = max(8, round(1024 * 901 / (n_patches + 1)))
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
     if a.batch <= 0:
-        # the eigensolver runs one workgroup per image, two per CU: pick the number of ViT forwards per step (1..4) whose
-        # image count best fills whole rounds of 2 x CUs workgroups
+        # the eigensolver runs one workgroup per image, two per CU: pick the number of ViT forwards per step (4..8: the
+        # copy of forward j + 1 hides under forward j) whose image count best fills whole rounds of 2 x CUs workgroups
         fill = lambda m: (m * a.vit_batch / (2 * ncu)) / math.ceil(m * a.vit_batch / (2 * ncu))
-        a.batch = max(range(1, 5), key=lambda m: (round(fill(m), 2), m)) * a.vit_batch
+        a.batch = max(range(4, 9), key=lambda m: (round(fill(m), 2), -m)) * a.vit_batch
     if a.dataset > 0:   # strong scaling: this rank's shard of a fixed set, in equal steps of at most the default batch
         shard = len(distributed.shard_indices(a.dataset, rank, world))
         n_steps = max(1, math.ceil(shard / a.batch))
