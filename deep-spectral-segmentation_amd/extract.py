@@ -346,13 +346,11 @@ def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, bloc
     worker processes, each call filling one page-locked /dev/shm block.  Yields ``(entries, block tensor u8, release)``
     in chunk order; the consumer enqueues its copies out of the block on the current stream and then calls
     ``release()`` - the block goes back to the workers once those copies have finished."""
-    import torch.multiprocessing as mp
     from collections import deque
 
     import time
     t_start = time.perf_counter()
-    with _spawn_without_main():
-        pool = mp.get_context(_start_method()).Pool(processes)   # first: the workers boot while the blocks are pinned
+    pool = _StaggeredPool(processes)                 # the first wave boots while the blocks are pinned
     blocks = _ShmBlocks(processes + 2, block_bytes)
     first = None
     try:
@@ -368,7 +366,7 @@ def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, bloc
                 return release
 
             while nxt < len(chunks) or pending:
-                while (free or len(blocks.paths) < blocks.count) and nxt < len(chunks):
+                while (free or len(blocks.paths) < blocks.count) and nxt < len(chunks) and len(pending) < pool.capacity() + 2:
                     b = free.popleft() if free else blocks.add()
                     if events[b] is not None:
                         events[b].synchronize()     # the copies out of this block have finished
@@ -382,8 +380,80 @@ def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, bloc
     finally:
         blocks.close()
         if os.environ.get("DSS_CLI_TIMING") and first is not None:
-            print(f"[dss] {fn.__name__}: {processes} workers, first chunk after {first:.2f} s, all {len(chunks)} chunks "
-                  f"after {time.perf_counter() - t_start:.2f} s")
+            print(f"[dss] {fn.__name__}: {processes} workers in waves of {_StaggeredPool.WAVE}, first chunk after {first:.2f} s, "
+                  f"all {len(chunks)} chunks after {time.perf_counter() - t_start:.2f} s")
+
+
+class _StaggeredPool:
+    """``processes`` torch-free worker processes started in WAVES: forty-eight interpreters booting at once took 3.1 s to
+    deliver their first chunk on the GPU box (twelve: 1.0 s) - so twelve start, and while they already work the next
+    twelve are started from a helper thread, and so on.  ``apply_async`` goes to the least loaded pool that is up;
+    ``capacity()`` = workers up so far (the producer keeps that many chunks + 2 in flight)."""
+
+    WAVE = 12
+
+    def __init__(self, processes: int):
+        import threading
+        import torch.multiprocessing as mp
+
+        self.ctx = mp.get_context(_start_method())
+        self.pools, self.load, self.sizes = [], [], []
+        self.lock = threading.Lock()
+        self.closing = False
+        self._start(min(self.WAVE, processes))
+        self.rest = processes - self.sizes[0]
+        self.thread = threading.Thread(target=self._grow, daemon=True)
+        self.thread.start()
+
+    def _start(self, n: int):
+        with _spawn_without_main():
+            pool = self.ctx.Pool(n)
+        with self.lock:
+            self.pools.append(pool)
+            self.load.append(0)
+            self.sizes.append(n)
+
+    def _grow(self):
+        import time
+        while self.rest > 0 and not self.closing:
+            try:   # the previous wave has finished booting when each of its workers has answered once
+                self.pools[-1].map(pthfast.noop, range(self.sizes[-1]), chunksize=1)
+            except Exception:
+                return
+            if self.closing:
+                return
+            n = min(self.WAVE, self.rest)
+            self._start(n)
+            self.rest -= n
+            time.sleep(0.01)
+
+    def capacity(self) -> int:
+        with self.lock:
+            return sum(self.sizes)
+
+    def apply_async(self, fn, args):
+        with self.lock:
+            i = min(range(len(self.pools)), key=lambda j: self.load[j] / self.sizes[j])
+            self.load[i] += 1
+            pool = self.pools[i]
+
+        def done(_res, i=i):
+            with self.lock:
+                self.load[i] -= 1
+
+        return pool.apply_async(fn, args, callback=done, error_callback=done)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.closing = True
+        self.thread.join(timeout=30)
+        for p in self.pools:
+            p.terminate() if exc[0] is not None else p.close()
+        for p in self.pools:
+            p.join()
+        return False
 
 
 def _iter_features(files, which_features: str, processes: int, window: int, device: Optional[torch.device] = None):
@@ -558,7 +628,9 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     clock = _StageClock()
     with clock("start savers"):   # first of all: the saver processes import torch while the model is being built
         saver = _AsyncSaver(processes=_io_processes(len(todo)))
-    decoders = _io_processes(len(todo), most=12) if saver.procs else 0   # ~1.1 ms of PIL per 480 x 480 JPEG
+    # ~6.5 ms of PIL per 480 x 480 JPEG (150 images/s per process): the ViT takes 12 000 images/s, the feature savers
+    # ~1 000 files/s each - dozens of decoders (started in waves of twelve, _StaggeredPool) before the GPU is what waits
+    decoders = _io_processes(len(todo), most=48) if saver.procs else 0
     with clock("model"):
         model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
                                                   weights=weights, synthetic_seed=synthetic_weights)
@@ -867,7 +939,7 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     bs = max(1, int(batch_size))
     n_pending, max_pending = 0, 8 * bs   # mixed-size datasets (VOC): bound the features waiting in host RAM
     # torch.load of a 1.4 MB feature file costs ~0.6 ms and torch.save of an 18 KB eigen file less: few workers do
-    nproc = _io_processes(len(mine), most=8)
+    nproc = _io_processes(len(mine), most=16)
     clock = _StageClock()
     with clock("start savers"):
         saver = _AsyncSaver(processes=min(nproc, 4))

@@ -31,6 +31,11 @@ class Unsupported(Exception):
     pass
 
 
+def noop(_=None):
+    """What a freshly started worker answers to say it is up (extract._StaggeredPool starts the next wave then)."""
+    return None
+
+
 class _StorageType:
     def __init__(self, name: str):
         self.dtype = np.dtype(_STORAGE_DTYPES[name])
