@@ -60,6 +60,13 @@ namespace dss {
 static constexpr int LBN = 32;            // output columns per W chunk (one MFMA column tile)
 static constexpr int LGELU_ILP = 2;       // float2 pairs advanced in lockstep by the GELU (4 spills registers)
 
+// LDS fragment read / counted wait with the order fixed by the source (see mfma_phase)
+template <int OFF, class V> __device__ __forceinline__ void lds_read_b128_at(V& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N, class V> __device__ __forceinline__ void lds_wait_for(V& v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -103,7 +110,7 @@ template <int NUNIT, int NXS, bool RES> struct LnSched {
 // operands against 1.68 on random ones (profiles/r01_mfma_ceiling_probe.txt): the number is a clock effect as much as an
 // A-stream effect, and neither full-line LDS-DMA loads of A nor two workgroups per CU moved the real-data time.
 template <int KS, int RT, int NW> struct LinCfg {
-  static_assert(KS * RT == 48 && KS % NW == 0, "the A operand of a wave is 48 fragments");
+  static_assert((KS * RT == 48 || KS * RT == 24) && KS % NW == 0, "the A operand of a wave is 48 (or, lab, 24) fragments");
   static constexpr int WAVES = NW, THREADS = 64 * NW;
   static constexpr int K = 16 * KS;
   static constexpr int ROWS_WAVE = 32 * RT;
@@ -117,7 +124,7 @@ template <int KS, int RT, int NW> struct LinCfg {
 // LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
 // res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
 template <class T, bool GELU, int KS, int RT, int NW, int LNM>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
                                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                                  const T* __restrict__ W,
                                                                  const T* __restrict__ bias, const float* __restrict__ aux,
@@ -371,18 +378,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
 
   // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
   //      p ^ ((r >> 1) & 7): writes 2-way, reads conflict-free) + (uniform base, 32-bit lane offset) addressing
+  // (the lane-derived addresses of the epilogue are rebuilt in it from a fresh lane id: six registers that would
+  //  otherwise be held through the MFMA phases, which need them for the third W-fragment buffer)
   unsigned char* stg = &Stg[wave][0];
-  unsigned char* stg_w = stg + li * 128 + 8 * hh;          // writer: row li (+32 for the second row tile)
-  const unsigned stg_x = 16u * ((li >> 1) & 7);
-  const int rq = lane >> 3, pq = lane & 7;                 // reader: row rq (+8 i), 16-byte piece pq
-  const unsigned stg_ro = (unsigned)(rq * 128 + 16 * (pq ^ (rq >> 1)));   // rows rq + 8 i: slot also ^ 4 for odd i
   // row-major C[M][N]: row stride 2N bytes, 64-column group p at byte 128 p of the row.  planar C[N/64][M][64]:
   // row stride 128 bytes, group p is a plane of 128 M bytes - a wave's 64 x 64 tile is 8 KB CONTIGUOUS (measured:
   // contiguous runs cost ~35 us of write-back per 531 MB where row-major full lines cost ~80 us)
   const size_t ldc = planar ? 128 : (size_t)(N * 2);
   const size_t gstride = planar ? (size_t)M * 128 : 128;
   unsigned char* cblk = reinterpret_cast<unsigned char*>(C) + (size_t)blockIdx.x * LBM * ldc;
-  const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
 
   f32x16 acc0, acc1;   // RT = 2: row tiles 0 / 1.  RT = 1: even / odd k-steps of the one row tile (two MFMA chains)
 
@@ -390,11 +394,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
   //      fragment is (bias[col], 0, ..) and its A fragment (1, 0, ..), both only in the hh = 0 half (k = 0), so the
   //      phase starts with a zero accumulator and no LDS round trip in front of the first MFMA.
   auto mfma_phase = [&](int c, int stage_next) {
-    const unsigned char* wb = &Ws[c & 1][16 * lane];
-    constexpr int PF = 2;                                  // W fragments in flight ahead of the MFMAs (3: measured equal)
+    // W fragments come out of LDS TWO k-steps ahead of the MFMAs that use them, and the order is pinned in assembly.  As plain
+    // C++ loads hipcc regroups them - two reads, then lgkmcnt waits straight behind them, then four MFMAs - so that every
+    // fourth MFMA waits out an LDS round trip: a wave alone on its SIMD (its partner in its epilogue) then runs at ~45 % of
+    // the matrix pipe and the partner's epilogue buys nothing (round-3 timeline: an MFMA phase takes 3 340 cycles whether
+    // or not the other wave is in one).  LDS returns in order: the wait for the fragment of step s leaves the reads of
+    // steps s + 1, s + 2 outstanding (counted waits; the fragment passes through the wait as an operand, which is what keeps
+    // its MFMAs behind it).
+    const unsigned wbase = (unsigned)(size_t)(lds_ptr_t)(&Ws[c & 1][0]) + 16u * (unsigned)lane;
+    constexpr int PF = 2;
     V8 f[PF + 1];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
+    static_for<PF>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read_b128_at<1024 * i>(f[i], wbase); });
     const float bcol = to_f32<T>(bias_next);
     float wcorr = 0.f;
     if constexpr (LNM == 0) {
@@ -413,9 +423,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < LKS; ++s) {
-      if (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
+    static_for<LKS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s + PF < LKS) lds_read_b128_at<1024 * (s + PF)>(f[(s + PF) % (PF + 1)], wbase);
+      lds_wait_for<(s + PF < LKS ? PF : LKS - 1 - s)>(f[s % (PF + 1)]);
       if (RT == 2) {
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
         acc1 = mfma32x32x16(f[s % (PF + 1)], a[RT - 1][s], acc1);
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
       } else {
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);
       }
-    }
+    });
     if constexpr (LNM == 0) {
       V8 fb, a_one;
 #pragma unroll
@@ -445,6 +456,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_kres_kernel(c
 
   // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 32 RT rows x 128 B
   auto epilogue = [&](int c) {
+    unsigned el;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));   // opaque: nothing below is hoisted
+    const unsigned eli = el & 31u, ehh = el >> 5;
+    unsigned char* stg_w = stg + eli * 128 + 8 * ehh;      // writer: row li (+32 for the second row tile)
+    const unsigned stg_x = 16u * ((eli >> 1) & 7);
+    const int rq = (int)(el >> 3), pq = (int)(el & 7);     // reader: row rq (+8 i), 16-byte piece pq
+    const unsigned stg_ro = (unsigned)(rq * 128 + 16 * (pq ^ (rq >> 1)));   // rows rq + 8 i: slot also ^ 4 for odd i
+    const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
     if constexpr (LNM != 0) {                              // acc *= 1 / sigma, in place: sigma lives in the hh = 1 lane of the pair
 #pragma unroll                                             // (rstd kept per row tile would be registers the GELU does not have)
       for (int t = 0; t < RT; ++t) {
@@ -645,5 +664,16 @@ extern "C" int dss_lnlinear_k768(float* x, const void* residual, int res_layout,
                                  void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(x, "dss_lnlinear_k768: null pointer");
   return dss::linear_kres<48, 1, 8>("dss_lnlinear_k768", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
+}
+#endif
+
+#ifdef DSS_LIN_LAB_RT1
+// Lab (scripts/probes): K = 384 with ONE 32-row tile per wave - 96 operand registers, so that THREE waves share a SIMD (two
+// workgroups of six waves per CU, 170 registers each) where the product runs two.  Plain Linear only.
+extern "C" int dss_linear_k384_rt1(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
+                                   int out_layout, void* stream) {
+  dss::launch_linear_kres<dss::f16, 24, 1, 6, 0>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu,
+                                                 out_layout == DSS_PLANAR64, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 #endif
