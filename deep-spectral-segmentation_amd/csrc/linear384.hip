@@ -404,7 +404,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(c
     const unsigned wbase = (unsigned)(size_t)(lds_ptr_t)(&Ws[c & 1][0]) + 16u * (unsigned)lane;
     constexpr int PF = 2;
     V8 f[PF + 1];
+#ifndef DSS_LIN_PLAIN_PREFETCH   // lab ablation (scripts/build_lablib.sh): the plain C++ loads hipcc regroups
     static_for<PF>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read_b128_at<1024 * i>(f[i], wbase); });
+#else
+    const unsigned char* wb = &Ws[c & 1][16 * lane];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
+#endif
     const float bcol = to_f32<T>(bias_next);
     float wcorr = 0.f;
     if constexpr (LNM == 0) {
@@ -425,8 +431,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(c
     __builtin_amdgcn_s_setprio(1);
     static_for<LKS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
+#ifndef DSS_LIN_PLAIN_PREFETCH
       if constexpr (s + PF < LKS) lds_read_b128_at<1024 * (s + PF)>(f[(s + PF) % (PF + 1)], wbase);
       lds_wait_for<(s + PF < LKS ? PF : LKS - 1 - s)>(f[s % (PF + 1)]);
+#else
+      if constexpr (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
+#endif
       if (RT == 2) {
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
         acc1 = mfma32x32x16(f[s % (PF + 1)], a[RT - 1][s], acc1);
