@@ -32,6 +32,12 @@ for STAGE in "$@"; do
       for i in "${!SW[@]}"; do echo "--- sweep $i: ${SW[$i]}"; timeout 400 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${SW[$i]} 2> gpurun_out/bench_sweep$i.err | tee gpurun_out/bench_sweep$i.json | bench_summary | head -3; done;;
     bench_quick2) timeout 600 python bench.py --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --distinct 256 ${BENCH_ARGS2:-} 2> gpurun_out/bench_quick2.err | tee gpurun_out/bench_quick2.json | bench_summary; tail -2 gpurun_out/bench_quick2.err;;
     bench) timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit: $?"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json;;
+    bench_c1) timeout 600 python bench.py --size 224 --cpu-images 8 --parity-images 8 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c1.json 2> gpurun_out/bench_c1.err; echo "bench_c1 exit: $?"; tail -2 gpurun_out/bench_c1.err; cut -c1-400 gpurun_out/bench_c1.json;;
+    bench_ds) for DS in ${DATASETS:-1250 10000}; do timeout 600 python bench.py --dataset $DS --cpu-images 0 --dino-like-steps 0 --companion-steps 0 2> gpurun_out/bench_ds$DS.err > gpurun_out/bench_ds$DS.json; python -c "
+import sys, json
+d = json.loads(open('gpurun_out/bench_ds$DS.json').read())
+print('dataset $DS:', {k: d[k] for k in ('value', 'ms_per_step', 'steps', 'scaling')}, d['config']['workload'])
+"; done;;
     bench_c3) timeout 900 python bench.py --model dino_vitb8 --K 15 --batch 512 --vit-batch 16 --cpu-images 2 --parity-images 2 --companion-steps 0 --dino-like-steps 0 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; echo "bench_c3 exit: $?"; tail -2 gpurun_out/bench_c3.err; cut -c1-600 gpurun_out/bench_c3.json;;
     prof)   # per-kernel time of the bench command (rocprofv3 kernel trace + stats); PROF_TAG names the output
       T=${PROF_TAG:-c2}; rm -rf gpurun_out/prof_$T && mkdir -p gpurun_out/prof_$T
