@@ -259,6 +259,20 @@ def test_lnlinear_rejects_bad_arguments():
     assert lib.dss_lnlinear_k384(x.data_ptr(), 0, 0, 1e-6, wg.data_ptr(), aux.data_ptr(), out.data_ptr(), 8, 64, 0, 0, 1, s) == 0
 
 
+def test_kfeatures_finalize_writes_into_caller_slices():
+    """`out=`: several ViT forwards fill ONE step's buffers (bench.py step_fed) - same values as the allocating form, nothing
+    outside the slices touched."""
+    g = torch.Generator().manual_seed(2)
+    kp = torch.randn(3, 11, 64, generator=g).to(DEV)
+    bias = torch.randn(64, generator=g).to(DEV)
+    want = hip.kfeatures_finalize(kp, bias)
+    bufs = (torch.full((5, 10, 64), 7.0, device=DEV), torch.full((5, 10, 64), 7.0, dtype=torch.float16, device=DEV),
+            torch.full((5, 10), 7.0, device=DEV))
+    got = hip.kfeatures_finalize(kp, bias, out=tuple(b[1:4] for b in bufs))
+    for w, gt, b in zip(want, got, bufs):
+        assert torch.equal(w, gt) and torch.equal(b[1:4], w) and bool((b[0] == 7).all()) and bool((b[4] == 7).all())
+
+
 # ----------------------------------------------------------------------------- attention
 def _attention_ref(qkv, heads, scale):
     b, t, _ = qkv.shape

@@ -145,6 +145,23 @@ def test_synthetic_inputs_are_portable():
     assert sd["patch_embed.proj.weight"].shape == (768, 3, 8, 8)
 
 
+def test_bench_chunking_is_balanced_and_keeps_the_copy_pipeline_fed():
+    """bench.chunk_counts: forwards of at most vit_batch images, equal to within one image, and at least four per step while
+    they stay above 256 images (a one-forward step cannot hide its H2D copy)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.chunk_counts(1250, 1018) == [313, 313, 312, 312]
+    assert bench.chunk_counts(4072, 1018) == [1018] * 4
+    assert bench.chunk_counts(2030, 290) == [290] * 7
+    assert bench.chunk_counts(100, 1018) == [100] and bench.chunk_counts(600, 1018) == [300, 300]
+    for cnt, vb in [(1, 5), (17, 5), (9999, 1018), (873, 291)]:
+        c = bench.chunk_counts(cnt, vb)
+        assert sum(c) == cnt and max(c) <= vb and max(c) - min(c) <= 1
+
+
 def test_wave_filling_batch_picks_whole_waves_of_workgroups():
     """vit.wave_filling_batch: images per ViT forward such that ceil(b * tokens / 512) workgroups of the K-resident
     Linear kernel fill whole waves of the CUs (pure arithmetic; no GPU)."""
@@ -166,7 +183,7 @@ def test_wave_filling_batch_picks_whole_waves_of_workgroups():
             assert eff >= base - 1e-9                                    # never worse than the plain target
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04"])
 def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp_path, rnd):
     """profiles/rNN_pmc_traffic.json (what bench.py reads for roofline.traffic) must follow from the committed
     rocprofv3 counter summaries: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch."""
@@ -181,7 +198,7 @@ def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp
                    capture_output=True)
     new, old = json.loads(out.read_text()), json.loads((prof / f"{rnd}_pmc_traffic.json").read_text())
     assert new["config"] == old["config"]
-    for key in ("attention", "layernorm", "laplacian_eigs", "affinity"):
+    for key in ("attention", "layernorm", "laplacian_eigs", "affinity") + (("lnlinear", "linear_kres") if rnd >= "r04" else ()):
         assert abs(new["kernels"][key]["hbm_bytes_per_launch"] - old["kernels"][key]["hbm_bytes_per_launch"]) < 1.0
         k = old["kernels"][key]
         assert abs((2 * k["fetch_size_kb"] + k["write_size_kb"]) * 1024 - k["hbm_bytes_per_launch"]) < 2048
