@@ -123,8 +123,10 @@ template <int KS, int RT, int NW> struct LinCfg {
 
 // LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
 // res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
-template <class T, bool GELU, int KS, int RT, int NW, int LNM>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
+// PIPE (lab, DSS_LIN_LAB_PIPE): ONE wave per SIMD owns all 512 registers and overlaps the epilogue of chunk c - 1 with the MFMAs
+// of chunk c (see the chunk loop).
+template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE = 0>
+__global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
                                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                                  const T* __restrict__ W,
                                                                  const T* __restrict__ bias, const float* __restrict__ aux,
@@ -542,6 +544,167 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(c
   //      last read in chunk c - 1, behind the barrier that ended it) and awaited (wait_dma) before the barrier that ends
   //      chunk c.
   const int nchunks = N / LBN;
+#ifdef DSS_LIN_LAB_PIPE
+  // Lab (scripts/probes/linear_pipe_lab.hip): TWO accumulator sets - the epilogue of chunk c - 1 (GELU, pack, patch, stores)
+  // is in the same basic block as the MFMAs of chunk c and a sched_group_barrier sequence asks hipcc to interleave them
+  // (RT MFMAs, 1 LDS read, DSS_LIN_LAB_PIPE VALU, ...).  NW = 4: with RT = 1 two workgroups share a CU (2 waves / SIMD, 256
+  // registers each); with RT = 2 ONE wave per SIMD owns all 512 registers.  Full blocks only.
+  if constexpr (PIPE != 0 && LNM == 0) {
+    f32x16 accA[RT], accB[RT];
+    constexpr int PF = DSS_LIN_LAB_PIPE_PF;
+    // the epilogue of one g (4 accumulator registers of every tile = NP float2) as ten short stages, one behind each MFMA
+    constexpr int NP = 2 * RT, NSTG = 10, MPG = (LKS * RT) / 4;   // MFMAs per g
+    static_assert(MPG >= NSTG, "one stage per MFMA");
+    f32x2 gx[NP], gz[NP], gq[NP];
+    auto epi_stage = [&](int c, const f32x16 (&acc)[RT], int g, auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st == 0) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          gx[2 * t] = f32x2{acc[t][4 * g], acc[t][4 * g + 1]};
+          gx[2 * t + 1] = f32x2{acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        }
+        if (GELU) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) { gz[j][0] = fabsf(gx[j][0]); gz[j][1] = fabsf(gx[j][1]); }
+        }
+      }
+      if constexpr (GELU) {
+        if constexpr (st == 1) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gz[j] = gz[j] * 0.70710678118654752f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gz[j] * 0.0000430638f + 0.0002765672f;
+        } else if constexpr (st == 2) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0001520143f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0092705272f;
+        } else if constexpr (st == 3) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0422820123f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0705230784f;
+        } else if constexpr (st == 4) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 1.0f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+        } else if constexpr (st == 5) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+        } else if constexpr (st == 6) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+#pragma unroll
+          for (int j = 0; j < NP / 2; ++j) { gq[j][0] = __builtin_amdgcn_rcpf(gq[j][0]); gq[j][1] = __builtin_amdgcn_rcpf(gq[j][1]); }
+        } else if constexpr (st == 7) {
+#pragma unroll
+          for (int j = NP / 2; j < NP; ++j) { gq[j][0] = __builtin_amdgcn_rcpf(gq[j][0]); gq[j][1] = __builtin_amdgcn_rcpf(gq[j][1]); }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gz[j] = gz[j] * 0.70710678118654752f;
+        } else if constexpr (st == 8) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = (1.0f - gq[j]) * gz[j];
+        }
+      }
+      if constexpr (st == 9) {
+        if (GELU) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gx[j] = gx[j] * 0.5f + gq[j];
+        }
+        unsigned char* stg_w = stg + li * 128 + 8 * hh;
+        const unsigned stg_x = 16u * ((li >> 1) & 7);
+        const unsigned half = 64u * (c & 1);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          V4 o0;
+          o0[0] = from_f32<T>(gx[2 * t][0]); o0[1] = from_f32<T>(gx[2 * t][1]); o0[2] = from_f32<T>(gx[2 * t + 1][0]); o0[3] = from_f32<T>(gx[2 * t + 1][1]);
+          *reinterpret_cast<V4*>(stg_w + ((half + 16 * g) ^ stg_x) + 4096 * t) = o0;
+        }
+      }
+    };
+    auto store_group = [&](int c) {       // c odd: the 64-column group c >> 1 is complete in the patch
+      const int rq = lane >> 3, pq = lane & 7;
+      const unsigned stg_ro = (unsigned)(rq * 128 + 16 * (pq ^ (rq >> 1)));
+      const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
+      unsigned char* cw = cblk + (size_t)(c >> 1) * gstride;
+#pragma unroll
+      for (int i = 0; i < Cfg::NSTORE; ++i)
+        __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
+                                    reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
+    };
+    // chunk c into `cur` while the epilogue of chunk c - 1 (in `prev`) runs in slices between its MFMAs: every SPU fragment
+    // steps one unit, hipcc told (sched_group_barrier) to alternate 1 MFMA / DSS_LIN_LAB_PIPE VALU inside the slice and
+    // (sched_barrier) to move nothing across its end
+    auto chunk = [&](int c, f32x16 (&cur)[RT], const f32x16 (&prev)[RT], bool with_prev, bool more) {
+      if (more) stage(c + 1);
+#if DSS_LIN_LAB_PIPE_RT == 2 && !defined(DSS_LIN_LAB_PIPE_NO_AGPR)
+      // the operand fragments live in the accumulation registers (the MFMA reads them there): the 256 architectural ones
+      // are for the two accumulator sets and the epilogue
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < LKS; ++s) asm volatile("" : "+a"(a[t][s]));
+#endif
+      const unsigned char* wb = &Ws[c & 1][16 * lane];
+      V8 f[PF + 1];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
+      const float bcol = to_f32<T>(bias_next);
+      bias_next = bias[min((c + 1) * LBN, N - LBN) + li];
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[t][r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<LKS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
+        static_for<RT>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int m = s * RT + t;                       // this chunk's m-th MFMA: stage m % MPG of g = m / MPG behind it
+          cur[t] = mfma32x32x16(f[s % (PF + 1)], a[t][s], cur[t]);
+          if constexpr (m % MPG < NSTG)
+            if (with_prev) epi_stage(c - 1, prev, m / MPG, std::integral_constant<int, m % MPG>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      V8 fb, a_one;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fb[e] = from_f32<T>((e == 0 && hh == 0) ? bcol : 0.0f);
+        a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) cur[t] = mfma32x32x16(fb, a_one, cur[t]);
+    };
+    stage(0);
+    wait_vm();
+    __syncthreads();
+    chunk(0, accA, accB, false, true);
+    wait_vm();
+    phase_barrier();
+    int c = 1;
+    for (; c + 1 < nchunks; c += 2) {
+      chunk(c, accB, accA, true, true);          // odd chunk beside the epilogue of the even one: half a 64-column group, no stores
+      wait_vm();
+      phase_barrier();
+      chunk(c + 1, accA, accB, true, true);      // even chunk beside the epilogue of the odd one, then that group's stores
+      store_group(c);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::NSTORE) : "memory");
+      phase_barrier();
+    }
+    chunk(c, accB, accA, true, false);
+    static_for<4>([&](auto gc) {
+      static_for<NSTG>([&](auto stc) { epi_stage(c, accB, decltype(gc)::value, stc); });
+    });
+    store_group(c);
+    return;
+  }
+#endif
   stage(0);
   wait_vm();
   __syncthreads();
@@ -581,15 +744,15 @@ __global__ __launch_bounds__(64) void lnlinear_prepare_kernel(const float* __res
   }
 }
 
-template <class T, int KS, int RT, int NW, int LNM>
+template <class T, int KS, int RT, int NW, int LNM, int PIPE = 0>
 static void launch_linear_kres(const void* A, float* X, const void* R, long r_ld, long r_plane, float eps, const void* W,
                                const void* bias, const float* aux, void* C, int M, int N, int gelu, int planar, hipStream_t s) {
   const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
   if (gelu)
-    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM, PIPE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
   else
-    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM, PIPE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
 }
 
@@ -684,6 +847,13 @@ extern "C" int dss_linear_k384_rt1(const void* A, const void* W, const void* bia
                                    int out_layout, void* stream) {
   dss::launch_linear_kres<dss::f16, 24, 1, 6, 0>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu,
                                                  out_layout == DSS_PLANAR64, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DSS_LIN_LAB_PIPE
+extern "C" int dss_linear_k384_pipe(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, void* stream) {
+  dss::launch_linear_kres<dss::f16, 24, DSS_LIN_LAB_PIPE_RT, 4, 0, 1>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu, 0, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 #endif

@@ -21,6 +21,8 @@ for STAGE in "$@"; do
     ln_ab) timeout 300 python scripts/debug/lnlinear_ab.py > gpurun_out/lnlinear_ab.log 2>&1; VIT_BATCH=580 timeout 300 python scripts/debug/lnlinear_ab.py >> gpurun_out/lnlinear_ab.log 2>&1; K=768 timeout 300 python scripts/debug/lnlinear_ab.py >> gpurun_out/lnlinear_ab.log 2>&1; cat gpurun_out/lnlinear_ab.log;;
     eigs_tests) timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 900 -rf --tb=short -k "eigs or golden or symmetric or sign_rule or starved" 2>&1 | tail -30 > gpurun_out/pytest_eigs.log; tail -12 gpurun_out/pytest_eigs.log;;
     cli) df -h /tmp /dev/shm | tail -2; timeout 1500 python scripts/cli_throughput.py ${CLI_N:-20480} > gpurun_out/cli_throughput.log 2>&1; echo "cli exit $?"; grep -v "Skipping\|^{" gpurun_out/cli_throughput.log | tail -25;;
+    pipe_lab) for P in scripts/probes/linear_pipe_lab_r*; do timeout 120 $P; done > gpurun_out/linear_pipe_lab.log 2>&1; cat gpurun_out/linear_pipe_lab.log;;
+    shadow) timeout 120 scripts/probes/mfma_valu_shadow_probe > gpurun_out/mfma_valu_shadow.log 2>&1; cat gpurun_out/mfma_valu_shadow.log;;
     lin_lab) timeout 300 scripts/probes/linear_lab > gpurun_out/linear_lab.log 2>&1; cat gpurun_out/linear_lab.log;;
     cu_mask) timeout 600 python scripts/debug/cu_mask_probe.py > gpurun_out/cu_mask_probe.log 2>&1; cat gpurun_out/cu_mask_probe.log;;
     tests) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -x 2>&1 | tail -80 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
