@@ -123,6 +123,13 @@ template <int KS, int RT, int NW> struct LinCfg {
 
 // LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
 // res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
+#ifdef DSS_LIN_LAB_STAGGER
+// Lab (scripts/debug/lin_stagger_ab.py): the workgroups of the FIRST round that are expected to be a CU's second tenant wait
+// before their prologue, so that the two workgroups of a CU are half a period apart from then on (one in its HBM-bound
+// prologue while the other is in its chunk loop) instead of in lockstep.  [0] = which workgroups (1: ids 256..511, 2: odd ids,
+// 3: ids with bit 3 set), [1] = the wait in wall-clock ticks (10 ns).
+__device__ int dss_lin_stagger[2];
+#endif
 // PIPE (lab, DSS_LIN_LAB_PIPE): ONE wave per SIMD owns all 512 registers and overlaps the epilogue of chunk c - 1 with the MFMAs
 // of chunk c (see the chunk loop).
 template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE = 0>
@@ -145,6 +152,16 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
   const bool block_full = mrem >= LBM;
 
   DSS_TL_DECL
+#ifdef DSS_LIN_LAB_STAGGER
+  {
+    const int mode = dss_lin_stagger[0], b = blockIdx.x;
+    const bool late = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : mode == 3 ? (b >> 3) & 1 : 0);
+    if (late) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)dss_lin_stagger[1]) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
   // ---- this lane's RT token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ----------------------------
   // Through the wave's own LDS patch, 64 columns at a time: LDS-DMA pieces of 8 rows x 128 B (FULL lines of A, 8 lanes per
   // row; 16-byte chunk c of row r lands at position c ^ ((r >> 1) & 7): the swizzle is applied to the source address) and
@@ -855,5 +872,12 @@ extern "C" int dss_linear_k384_rt1(const void* A, const void* W, const void* bia
 extern "C" int dss_linear_k384_pipe(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, void* stream) {
   dss::launch_linear_kres<dss::f16, 24, DSS_LIN_LAB_PIPE_RT, 4, 0, 1>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu, 0, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DSS_LIN_LAB_STAGGER
+extern "C" int dss_linear_set_stagger(int mode, int ticks) {
+  const int v[2] = {mode, ticks};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dss::dss_lin_stagger), v, sizeof(v)) == hipSuccess ? 0 : -2;
 }
 #endif
