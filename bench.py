@@ -48,7 +48,9 @@ MFMA32_PEAK_TF = 157.3      # fp32 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=12,
+                    help="timed steps (12 x 4072 images = 3.6 s at the headline config: with 4, the first chunk's exposed "
+                         "H2D copy and the end-of-run collection weigh 17 ms per step, with 12 or more 5-6 ms)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0,
                     help="images per step per GPU (0 = 4..8 ViT forwards, whichever fills whole rounds of eigensolver "
