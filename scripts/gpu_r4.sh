@@ -24,6 +24,8 @@ for STAGE in "$@"; do
     pipe_lab) for P in scripts/probes/linear_pipe_lab_r*; do timeout 120 $P; done > gpurun_out/linear_pipe_lab.log 2>&1; cat gpurun_out/linear_pipe_lab.log;;
     shadow) timeout 120 scripts/probes/mfma_valu_shadow_probe > gpurun_out/mfma_valu_shadow.log 2>&1; cat gpurun_out/mfma_valu_shadow.log;;
     stagger) DSS_HIP_LIBRARY=scripts/lablib/libdss_hip_stagger.so timeout 300 python scripts/debug/lin_stagger_ab.py > gpurun_out/lin_stagger.log 2>&1; cat gpurun_out/lin_stagger.log;;
+    lib_ab)   # LIBS="tag1 tag2": scripts/debug/lin_ab2.py with the product library, then with each scripts/lablib/libdss_hip_<tag>.so, twice
+      for rep in 1 2; do VIT_BATCH=${VIT_BATCH:-290} timeout 200 python scripts/debug/lin_ab2.py; for L in ${LIBS:-}; do VIT_BATCH=${VIT_BATCH:-290} DSS_HIP_LIBRARY=scripts/lablib/libdss_hip_$L.so timeout 200 python scripts/debug/lin_ab2.py; done; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/lib_ab.log;;
     lin_lab) timeout 300 scripts/probes/linear_lab > gpurun_out/linear_lab.log 2>&1; cat gpurun_out/linear_lab.log;;
     cu_mask) timeout 600 python scripts/debug/cu_mask_probe.py > gpurun_out/cu_mask_probe.log 2>&1; cat gpurun_out/cu_mask_probe.log;;
     tests) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -x 2>&1 | tail -80 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
