@@ -10,13 +10,23 @@ MI355X_MICROARCH.md section HBM (gfx950 counts 128-byte requests as 64 B; checke
 elementwise torch kernel whose traffic is known)."""
 import csv
 import json
+import re
 import sys
 
+def _kres_lnm(name):
+    """LNM of a linear_kres_kernel instance (None for other kernels): the template arguments after the element type are
+    <GELU, KS, RT, NW, LNM[, PIPE]> - mangled ...linear_kres_kernelIDF16_Lb1ELi24ELi2ELi4ELi<LNM>E[Li0E]EEvPK...; 0 = plain
+    Linear, 1 / 2 = LayerNorm prologue."""
+    m = re.search(r"linear_kres_kernelI\w+?_?Lb[01]ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
+    if not m:   # demangled: dss::linear_kres_kernel<_Float16, true, 24, 2, 4, 2, 0>
+        m = re.search(r"linear_kres_kernel<[^,>]+,\s*\w+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", name)
+    return int(m.group(1)) if m else None
+
+
 KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name (or a predicate on it)
-    # one template, two bench keys: the last template argument is LNM (0 = plain Linear, 1 / 2 = LayerNorm prologue)
-    # (mangled names: ...linear_kres_kernelIDF16_Lb1ELi24ELi2ELi4ELi<LNM>EEEv...)
-    "linear_kres": lambda n: "linear_kres_kernel" in n and "ELi0EEEv" in n,
-    "lnlinear": lambda n: "linear_kres_kernel" in n and "EEEv" in n and "ELi0EEEv" not in n,
+    # one template, two bench keys
+    "linear_kres": lambda n: _kres_lnm(n) == 0,
+    "lnlinear": lambda n: _kres_lnm(n) in (1, 2),
     "attention": "attn_fwd",
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_",
