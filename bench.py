@@ -99,6 +99,9 @@ def parse():
                     help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
     ap.add_argument("--no-fuse-ln", action="store_true",
                     help="A/B arm: standalone residual + LayerNorm passes instead of the fused dss_lnlinear_* prologue")
+    ap.add_argument("--no-fuse-k", action="store_true",
+                    help="A/B arm: the hooked block's K projection as LayerNorm + library GEMM + dss_kfeatures_finalize "
+                         "instead of the one dss_lnlinear_kfeatures_k384 kernel")
     ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
                     help="erf = DINO's GELU (default, the reported configuration); tanh_fused = hipBLASLt epilogue "
                          "(tanh approximation, NOT the reference function; diagnostic only)")
@@ -335,15 +338,15 @@ def summarize_timers(timers, n_patches, dim, depth_attn, affinity_mode="fused"):
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
                 byts = (4.0 * m["n"] * m["d"] + m.get("w_bytes", 4) / 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        elif name in ("linear_kres", "lnlinear", "library_gemm"):
+        elif name in ("linear_kres", "lnlinear", "lnlinear_kfeatures", "library_gemm"):
             # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input); the fused
             # residual + LayerNorm + Linear kernel additionally reads x f32 + the pending branch output and writes x back
             flops = np.mean([2.0 * m["m"] * m["n"] * m["k"] for m in metas])
             outb = np.mean([2.0 * m["m"] * m["n"] for m in metas])
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s",
                          output_GBs=round(outb / (avg * 1e-3) / 1e9, 1))
-            if name == "lnlinear":
-                hbm = np.mean([m["m"] * m["k"] * (10.0 if m["res"] else 4.0) + 2.0 * m["m"] * m["n"] for m in metas])
+            if name in ("lnlinear", "lnlinear_kfeatures"):   # (the hand-over writes 4 + 2 bytes per output element)
+                hbm = np.mean([m["m"] * m["k"] * (10.0 if m["res"] else 4.0) + (6.0 if "t" in m else 2.0) * m["m"] * m["n"] for m in metas])
                 entry["hbm_GBs"] = round(hbm / (avg * 1e-3) / 1e9, 1)
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
@@ -502,7 +505,7 @@ def main():
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
-                    gemm_tuning=a.gemm_tuning)
+                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -654,7 +657,7 @@ def main():
             # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
             "layernorm_launches_per_forward": round(kern.get("layernorm", {}).get("launches", 0) / max(n_forwards, 1), 2),
             "library_gemm_ms_per_step": round(kern.get("library_gemm", {}).get("total_ms", 0.0) / steps_out, 3),
-            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln},
+            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k},
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
             "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
@@ -673,7 +676,7 @@ def main():
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
-                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning)
+                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

@@ -132,12 +132,18 @@ __device__ int dss_lin_stagger[2];
 #endif
 // PIPE (lab, DSS_LIN_LAB_PIPE): ONE wave per SIMD owns all 512 registers and overlaps the epilogue of chunk c - 1 with the MFMAs
 // of chunk c (see the chunk loop).
-template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE = 0>
-__global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
-                                                                 const T* __restrict__ R, long r_ld, long r_plane, float eps,
-                                                                 const T* __restrict__ W,
-                                                                 const T* __restrict__ bias, const float* __restrict__ aux,
-                                                                 T* __restrict__ C, int M, int N, int planar) {
+// MODE 2 (K-feature hand-over, dss_lnlinear_kfeatures_k384): the output of the LAST block's K projection leaves as what the
+// caller and the affinity build need - token rows b * Tn + t, t >= 1, go to row b * (Tn - 1) + t - 1 of k32 (fp32, straight
+// from the accumulators: 16-byte pieces, a 32-column chunk of a row is one 128-byte line written by one wave), of C = k16
+// (through the transpose patch, as every other output) and rnorm = 1 / max(|k16 row|, eps); CLS rows are computed and dropped.
+struct KfOut { float* k32; float* rnorm; int Tn; float eps; };
+
+template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE>
+__device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float* __restrict__ X,
+                                                 const T* __restrict__ R, long r_ld, long r_plane, float eps,
+                                                 const T* __restrict__ W,
+                                                 const T* __restrict__ bias, const float* __restrict__ aux,
+                                                 T* __restrict__ C, int M, int N, int planar, const KfOut kf) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
   typedef LinCfg<KS, RT, NW> Cfg;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
   // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
   // Ragged workgroups predicate their stores (unknown count): they wait for everything.
   auto wait_dma = [&](int c_stored) {
-    if (block_full && (c_stored & 1)) {
+    if (PIPE != 2 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
       if (Cfg::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -483,6 +489,36 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // ---- K-feature hand-over (PIPE == 2, see KfOut): this lane's two accumulator rows -> output rows, their sums of squares
+  float kss[RT];
+  unsigned kmagic = 0;                                     // gr / Tn = umulhi(gr, kmagic) for gr * Tn < 2^32 (host-checked)
+  if constexpr (PIPE == 2) {
+    kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) kss[t] = 0.f;
+  }
+  // output row of accumulator row (tile t, lane row l31), rebuilt where it is used (a register pair held through the MFMA
+  // phases otherwise): -1 = CLS or past M
+  auto kf_row = [&](int t, unsigned l31) -> int {           // (one division: rows l31 and l31 + 32 straddle at most one image boundary)
+    const unsigned gr0 = (unsigned)blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + l31, gr = gr0 + 32 * t;
+    const unsigned b0 = __umulhi(gr0, kmagic);
+    const unsigned cls0 = b0 * (unsigned)kf.Tn, cls1 = cls0 + (unsigned)kf.Tn;
+    return ((int)gr < M && gr != cls0 && gr != cls1) ? (int)(gr - b0 - 1u - (gr >= cls1 ? 1u : 0u)) : -1;
+  };
+  auto kf_finish = [&]() {
+    unsigned fl;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(fl));   // fresh lane id (see the epilogue)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const unsigned u = __float_as_uint(kss[t]);
+      const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row's columns: lane ^ 32
+      const unsigned lo = r[0], hi = r[1];
+      const float tot = __uint_as_float(lo) + __uint_as_float(hi);
+      const int orow = kf_row(t, fl & 31u);
+      if (fl < 32u && orow >= 0) kf.rnorm[orow] = 1.0f / fmaxf(sqrtf(tot), kf.eps);
+    }
+  };
+
   // ---- epilogue of chunk c: (GELU,) f16 pack, transpose patch; after every second chunk store 32 RT rows x 128 B
   auto epilogue = [&](int c) {
     unsigned el;
@@ -515,6 +551,48 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
     asm volatile("" :: "v"(acc0), "v"(acc1));
     return;
 #endif
+    if constexpr (PIPE == 2) {
+      // (uniform base in SGPRs + 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic per lane)
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const unsigned half2 = 64u * (c & 1);
+      unsigned char* const k32c = reinterpret_cast<unsigned char*>(kf.k32) + (size_t)(c * LBN * 4);      // uniform
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int orow = kf_row(t, eli);
+        const unsigned koff = (unsigned)orow * (unsigned)(LK * 4) + 16u * ehh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4v v = t == 0 ? f32x4v{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]}
+                                  : f32x4v{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+          if (orow >= 0) *reinterpret_cast<f32x4v*>(k32c + koff + 32 * g) = v;
+          V4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = from_f32<T>(v[i]);
+            const float rr = to_f32<T>(o[i]);
+            kss[t] = fmaf(rr, rr, kss[t]);
+          }
+          *reinterpret_cast<V4*>(stg_w + ((half2 + 16 * g) ^ stg_x) + 4096 * t) = o;
+          __builtin_amdgcn_sched_barrier(0);                   // one piece at a time: nothing of the next one is started early
+        }
+      }
+      if (!(c & 1)) return;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read (other lanes' data)
+      unsigned char* const k16c = reinterpret_cast<unsigned char*>(C) + (size_t)((c >> 1) * 128);          // uniform
+      // rows rq + 8 i of this wave's 64: at most ONE image boundary among them (Tn > 64, host-checked) - one division
+      const unsigned gr0 = (unsigned)blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + rq;
+      const unsigned b0 = __umulhi(gr0, kmagic);
+      const unsigned cls0 = b0 * (unsigned)kf.Tn, cls1 = cls0 + (unsigned)kf.Tn;      // the CLS rows of image b0 and b0 + 1
+      const unsigned off0 = (gr0 - b0 - 1u) * (unsigned)(LK * 2) + 16u * (unsigned)pq;
+#pragma unroll
+      for (int i = 0; i < Cfg::NSTORE; ++i) {
+        const unsigned gr = gr0 + 8 * i;
+        const unsigned off = off0 + (unsigned)(8 * i * LK * 2) - (gr >= cls1 ? (unsigned)(LK * 2) : 0u);
+        if ((int)gr < M && gr != cls0 && gr != cls1)
+          *reinterpret_cast<V8*>(k16c + off) = *reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i);
+      }
+      return;
+    }
     const unsigned half = 64u * (c & 1);                   // which half of the 128-byte row
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -566,7 +644,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
   // is in the same basic block as the MFMAs of chunk c and a sched_group_barrier sequence asks hipcc to interleave them
   // (RT MFMAs, 1 LDS read, DSS_LIN_LAB_PIPE VALU, ...).  NW = 4: with RT = 1 two workgroups share a CU (2 waves / SIMD, 256
   // registers each); with RT = 2 ONE wave per SIMD owns all 512 registers.  Full blocks only.
-  if constexpr (PIPE != 0 && LNM == 0) {
+  if constexpr (PIPE == 1 && LNM == 0) {
     f32x16 accA[RT], accB[RT];
     constexpr int PF = DSS_LIN_LAB_PIPE_PF;
     // the epilogue of one g (4 accumulator registers of every tile = NP float2) as ten short stages, one behind each MFMA
@@ -735,7 +813,25 @@ __global__ __launch_bounds__(64 * NW, (PIPE && RT == 2) || NW == 8 ? 1 : 2) void
     phase_barrier();
     DSS_TL_MARK(3)
   }
+  if constexpr (PIPE == 2) kf_finish();
   DSS_TL_FLUSH
+}
+
+template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE = 0>
+__global__ __launch_bounds__(64 * NW, (PIPE == 1 && RT == 2) || NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
+                                                                 const T* __restrict__ R, long r_ld, long r_plane, float eps,
+                                                                 const T* __restrict__ W,
+                                                                 const T* __restrict__ bias, const float* __restrict__ aux,
+                                                                 T* __restrict__ C, int M, int N, int planar) {
+  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f});
+}
+
+// The K = 384 kernel in its hand-over mode (see KfOut): N = 384 output columns, no bias pointer (it rides in aux).
+template <class T, int LNM>
+__global__ __launch_bounds__(256, 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
+                                                            const T* __restrict__ W, const float* __restrict__ aux, T* __restrict__ k16,
+                                                            float* __restrict__ k32, float* __restrict__ rnorm, int M, int Tn, float norm_eps) {
+  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps});
 }
 
 // One wave per output column: Wg[n][k] = T(W[n][k] gamma[k]);  aux[n] = (-sum_k float(Wg[n][k]), bias[n] + sum_k W[n][k] beta[k])
@@ -847,6 +943,29 @@ extern "C" int dss_lnlinear_k384(float* x, const void* residual, int res_layout,
                                  void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(x, "dss_lnlinear_k384: null pointer");
   return dss::linear_kres<24, 2, 4>("dss_lnlinear_k384", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
+}
+
+extern "C" int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                                           float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream) {
+  DSS_REQUIRE(x && Wg && aux && k32 && k16 && rnorm, "dss_lnlinear_kfeatures_k384: null pointer");
+  DSS_REQUIRE(M > 0 && T > 64 && M % T == 0, "dss_lnlinear_kfeatures_k384: need M = B * T token rows, T > 64 (M=%d T=%d)", M, T);
+  DSS_REQUIRE((long)M * T < 4294967296L && (long)M * 1536 < 4294967296L,
+              "dss_lnlinear_kfeatures_k384: M=%d x T=%d exceeds the 32-bit row arithmetic of the hand-over epilogue", M, T);
+  DSS_REQUIRE(!residual || res_layout == DSS_ROW_MAJOR || res_layout == DSS_PLANAR64,
+              "dss_lnlinear_kfeatures_k384: res_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", res_layout);
+  DSS_REQUIRE(eps >= 0.f && norm_eps >= 0.f && (const void*)x != residual && (void*)x != (void*)k32, "dss_lnlinear_kfeatures_k384: eps < 0 or aliased buffers");
+  typedef dss::LinCfg<24, 2, 4> Cfg;
+  const long r_ld = res_layout == DSS_PLANAR64 ? 64 : Cfg::K, r_plane = res_layout == DSS_PLANAR64 ? 64L * M : 64;
+  const int blocks = dss::ceil_div(M, Cfg::ROWS);
+  hipStream_t s = (hipStream_t)stream;
+  if (residual)
+    hipLaunchKernelGGL((dss::kfeat_kres_kernel<dss::f16, 2>), dim3(blocks), dim3(256), 0, s, x, (const dss::f16*)residual, r_ld, r_plane, eps,
+                       (const dss::f16*)Wg, aux, (dss::f16*)k16, k32, rnorm, M, T, norm_eps);
+  else
+    hipLaunchKernelGGL((dss::kfeat_kres_kernel<dss::f16, 1>), dim3(blocks), dim3(256), 0, s, x, (const dss::f16*)nullptr, r_ld, r_plane, eps,
+                       (const dss::f16*)Wg, aux, (dss::f16*)k16, k32, rnorm, M, T, norm_eps);
+  DSS_CHECK_LAUNCH("dss_lnlinear_kfeatures_k384");
+  return DSS_OK;
 }
 
 #ifndef DSS_LIN_LAB_MIN

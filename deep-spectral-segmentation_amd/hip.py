@@ -38,6 +38,8 @@ SYMBOLS = {
                                   c_int, c_int, c_void_p]),
     "dss_lnlinear_k768": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
+    "dss_lnlinear_kfeatures_k384": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -76,7 +78,7 @@ _lib: Optional[ctypes.CDLL] = None
 # launches per step is not a measurement any more but a load) - and count every launch in TIMERS["_launches"][name].
 TIMERS: Optional[dict] = None
 TIMER_SAMPLE = 1
-TIMER_ALWAYS = ("laplacian_eigs", "affinity", "kfeatures_finalize", "layernorm")   # a handful of launches per step: all timed
+TIMER_ALWAYS = ("laplacian_eigs", "affinity", "kfeatures_finalize", "lnlinear_kfeatures", "layernorm")   # a handful of launches per step: all timed
 
 
 class _timed:
@@ -290,6 +292,36 @@ def lnlinear(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor
                                               _dev(aux, "aux"), _dev(out, "out"), m, n, int(gelu),
                                               PLANAR64 if planar else ROW_MAJOR, dtype_code(wg.dtype), _stream()), entry)
     return out
+
+
+def lnlinear_kfeatures(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor, aux: torch.Tensor, eps: float,
+                       norm_eps: float = 1e-12, residual_planar: bool = False, out=None):
+    """The hooked block's K projection from the residual stream to the hand-over, in one kernel
+    (``dss_lnlinear_kfeatures_k384``): ``x`` f32 ``[B, T, 384]`` (``+= residual`` in place), ``wg, aux`` =
+    ``lnlinear_prepare`` of the K rows of the qkv weight -> ``(k32 [B, T-1, 384] f32, k16 the same in f16, rnorm [B, T-1])``
+    with the CLS row dropped - what ``layernorm`` + a library GEMM + ``kfeatures_finalize`` produce in three passes.
+    ``out``: the three destinations, as for ``kfeatures_finalize``."""
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == 384 and x.is_contiguous()
+    assert wg.dtype == torch.float16 and tuple(wg.shape) == (384, 384) and tuple(aux.shape) == (384, 2)
+    b, t, d = x.shape
+    if t <= 64:
+        raise ValueError(f"lnlinear_kfeatures: needs more than 64 tokens per image (got {t})")
+    if residual is not None:
+        assert residual.dtype == torch.float16 and tuple(residual.shape) == ((d // 64, b * t, 64) if residual_planar else (b, t, d))
+    if out is not None:
+        k32, k16, rn = out
+        assert tuple(k32.shape) == tuple(k16.shape) == (b, t - 1, d) and tuple(rn.shape) == (b, t - 1)
+        assert k32.dtype == torch.float32 and k16.dtype == torch.float16 and rn.dtype == torch.float32
+    else:
+        k32 = torch.empty((b, t - 1, d), dtype=torch.float32, device=x.device)
+        k16 = torch.empty((b, t - 1, d), dtype=torch.float16, device=x.device)
+        rn = torch.empty((b, t - 1), dtype=torch.float32, device=x.device)
+    with _timed("lnlinear_kfeatures", m=b * t, n=d, k=d, t=t, res=residual is not None):
+        _check(load_library().dss_lnlinear_kfeatures_k384(
+            _dev(x, "x"), 0 if residual is None else _dev(residual, "residual"), PLANAR64 if residual_planar else ROW_MAJOR,
+            float(eps), _dev(wg, "Wg"), _dev(aux, "aux"), _dev(k32, "k32"), _dev(k16, "k16"), _dev(rn, "rnorm"), b * t, t,
+            float(norm_eps), _stream()), "dss_lnlinear_kfeatures_k384")
+    return k32, k16, rn
 
 
 def linear_k384(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,

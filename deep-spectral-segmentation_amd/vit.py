@@ -84,7 +84,7 @@ class DinoViT:
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
-                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table"):
+                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -109,6 +109,10 @@ class DinoViT:
             raise ValueError("linear_kres must be 0, 1 or 2")
         self.linear_k384 = int(linear_kres)
         self.fuse_ln = bool(fuse_ln)
+        # fuse_k (default, with fuse_ln, D = 384, f16): the hooked block's norm1 -> K projection -> CLS drop / f16 copy /
+        # inverse norms is ONE kernel (dss_lnlinear_kfeatures_k384) on the pipeline's path (`extract_k_f16`) instead of
+        # LayerNorm + library GEMM + dss_kfeatures_finalize
+        self.fuse_k = bool(fuse_k)
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -151,6 +155,8 @@ class DinoViT:
                 if d == 384:
                     blk["qkv_wg"], blk["qkv_aux"] = hip.lnlinear_prepare(f32(sd[p + "attn.qkv.weight"]), f32(sd[p + "attn.qkv.bias"]),
                                                                          blk["n1w"], blk["n1b"], dtype)
+                if d == 384 and self.fuse_k and dtype == torch.float16:
+                    blk["k_wg"], blk["k_aux"] = hip.lnlinear_prepare(blk["k_w32"], blk["k_b32"], blk["n1w"], blk["n1b"], dtype)
                 if self.linear_k384 >= 2 and self.gelu == "erf":
                     blk["fc1_wg"], blk["fc1_aux"] = hip.lnlinear_prepare(f32(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"]),
                                                                          blk["n2w"], blk["n2b"], dtype)
@@ -271,6 +277,9 @@ class DinoViT:
         if self.k_proj_fp32:  # all-fp32 K projection (3x slower GEMM; same operand rounding as nowhere else)
             h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)
             k = F.linear(h32, blk["k_w32"], blk["k_b32"])
+        elif _finalize and "k_wg" in blk and t > 64:
+            # residual add + norm1 + K projection + the whole hand-over in one kernel (fp32 features straight from the accumulators)
+            return hip.lnlinear_kfeatures(x, pending, blk["k_wg"], blk["k_aux"], LN_EPS, out=_out)
         else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
             hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             with hip._timed("library_gemm", m=b * t, n=d, k=d, what="k_proj"):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DSS_ABI_VERSION 4
+#define DSS_ABI_VERSION 5
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -109,6 +109,18 @@ int dss_lnlinear_k384(float* x, const void* residual, int res_layout, float eps,
                       int M, int N, int gelu, int out_layout, int dtype, void* stream);
 int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux, void* C,
                       int M, int N, int gelu, int out_layout, int dtype, void* stream);
+
+/* ---- a6'' + a8 + a9: the LAST hooked block's K projection, from the residual stream to what the caller and the affinity
+ * build take over (extract/extract.py:89-98: the forward hook on blocks[which_block].attn.qkv, `k` of its output, CLS
+ * dropped; :148 F.normalize's norms).  dss_lnlinear_k384 with the K rows of the qkv weight (N = K = 384, folded by
+ * dss_lnlinear_prepare) whose epilogue writes, for token row b * T + t with t >= 1, output row b * (T - 1) + t - 1 of
+ *   k32   [M / T * (T - 1), 384] f32  the features (fp32 accumulators, never rounded),
+ *   k16   the same rounded to f16, and
+ *   rnorm [M / T * (T - 1)]  = 1 / max(|k16 row|_2, norm_eps)   (the norm of the ROUNDED row: w_ii = 1 exactly);
+ * CLS rows are computed and dropped.  x [M, 384] f32 is updated in place (x += residual) as in dss_lnlinear_k384.
+ * f16 operands only; 64 < T, M * T < 2^32.  Replaces dss_layernorm_fwd + a library GEMM + dss_kfeatures_finalize. */
+int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                                float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream);
 
 /* ---- a10: row L2 normalisation -------------------------------------------------------------
  * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */

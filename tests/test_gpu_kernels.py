@@ -259,6 +259,60 @@ def test_lnlinear_rejects_bad_arguments():
     assert lib.dss_lnlinear_k384(x.data_ptr(), 0, 0, 1e-6, wg.data_ptr(), aux.data_ptr(), out.data_ptr(), 8, 64, 0, 0, 1, s) == 0
 
 
+@pytest.mark.parametrize("b,t", [(2, 901), (1, 197), (3, 65), (5, 130), (1, 3601), (7, 257)])
+@pytest.mark.parametrize("res", [None, "rows", "planar"])
+def test_lnlinear_kfeatures_matches_the_three_kernels_it_replaces(b, t, res):
+    """dss_lnlinear_kfeatures_k384 (x += r; norm1; K projection; CLS drop; f16 copy; inverse norms) against the fp64
+    composition, and against LayerNorm + GEMM + dss_kfeatures_finalize: the fp32 features to the operand-rounding bar of the
+    other fused kernels, k16 = f16(k32) exactly, rnorm = 1 / |k16 row| to fp32 rounding, the residual stream the same fp32 sum,
+    every output row written (image boundaries fall inside workgroups and inside waves at these shapes)."""
+    k = n = 384
+    m = b * t
+    x, r, w, bias, gamma, beta = _lnlinear_case(m, n, k, torch.float16, 5 * b + t)
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), torch.float16)
+    xd = x.view(b, t, k).to(DEV)
+    rd = None if res is None else (_to_planar(r).to(DEV) if res == "planar" else r.view(b, t, k).to(DEV))
+    sentinel = 7.0
+    bufs = (torch.full((b + 2, t - 1, k), sentinel, device=DEV), torch.full((b + 2, t - 1, k), sentinel, dtype=torch.float16, device=DEV),
+            torch.full((b + 2, t - 1), sentinel, device=DEV))
+    k32, k16, rn = hip.lnlinear_kfeatures(xd, rd, wg, aux, 1e-6, residual_planar=(res == "planar"), out=tuple(u[1:1 + b] for u in bufs))
+    torch.cuda.synchronize()
+    xsum = x if res is None else x + r.float()
+    assert torch.equal(xd.cpu().view(m, k), xsum)
+    for u in bufs:   # nothing outside the slices
+        assert bool((u[0] == sentinel).all()) and bool((u[1 + b:] == sentinel).all())
+    ref = F.linear(F.layer_norm(xsum.double(), (k,), gamma.double(), beta.double(), 1e-6), w.double(), bias.double())
+    ref = ref.view(b, t, n)[:, 1:]
+    tol = 1.5e-3 * max(1.0, ref.abs().max().item())
+    assert (k32.cpu().double() - ref).abs().max().item() <= tol
+    assert torch.equal(k16, k32.half())
+    want_rn = 1.0 / k16.double().norm(dim=-1).clamp_min(1e-12)
+    assert ((rn.double() - want_rn).abs() / want_rn).max().item() <= 1e-6
+    # the three-kernel path on the same inputs: same quantity, its own roundings
+    xb = x.view(b, t, k).to(DEV)
+    h = hip.layernorm(xb, gamma.to(DEV), beta.to(DEV), 1e-6, torch.float16, residual=rd, residual_planar=(res == "planar"))
+    kp = torch.mm(h.view(m, k), w.half().to(DEV).t(), out_dtype=torch.float32).view(b, t, n)
+    o32, o16, orn = hip.kfeatures_finalize(kp, bias.to(DEV))
+    assert (o32.cpu().double() - ref).abs().max().item() <= tol
+    assert (k32 - o32).abs().max().item() <= 2 * tol
+
+
+def test_lnlinear_kfeatures_rejects_bad_arguments():
+    x = torch.zeros(2, 65, 384, device=DEV)
+    wg, aux = torch.zeros(384, 384, dtype=torch.float16, device=DEV), torch.zeros(384, 2, device=DEV)
+    k32, k16, rn = torch.zeros(2, 64, 384, device=DEV), torch.zeros(2, 64, 384, dtype=torch.float16, device=DEV), torch.zeros(2, 64, device=DEV)
+    lib, s = hip.load_library(), torch.cuda.current_stream().cuda_stream
+    f = lib.dss_lnlinear_kfeatures_k384
+    ok = (x.data_ptr(), 0, 0, 1e-6, wg.data_ptr(), aux.data_ptr(), k32.data_ptr(), k16.data_ptr(), rn.data_ptr(), 130, 65, 1e-12, s)
+    assert f(*ok) == 0
+    assert f(*ok[:9], 130, 64, 1e-12, s) == -1          # T <= 64: the row remap assumes one image boundary per 64 rows
+    assert f(*ok[:9], 131, 65, 1e-12, s) == -1          # M not a whole number of images
+    assert f(*ok[:6], 0, *ok[7:]) == -1                 # no k32
+    assert f(*ok[:2], 7, *ok[3:]) == 0                  # (res_layout is not read without a residual)
+    with pytest.raises(ValueError):
+        hip.lnlinear_kfeatures(torch.zeros(1, 64, 384, device=DEV), None, wg, aux, 1e-6)
+
+
 def test_kfeatures_finalize_writes_into_caller_slices():
     """`out=`: several ViT forwards fill ONE step's buffers (bench.py step_fed) - same values as the allocating form, nothing
     outside the slices touched."""
