@@ -345,9 +345,14 @@ def summarize_timers(timers, n_patches, dim, depth_attn, affinity_mode="fused"):
             outb = np.mean([2.0 * m["m"] * m["n"] for m in metas])
             entry.update(bound="mfma", achieved=flops / (avg * 1e-3) / 1e12, peak=MFMA16_PEAK_TF, unit="TFLOP/s",
                          output_GBs=round(outb / (avg * 1e-3) / 1e9, 1))
-            if name in ("lnlinear", "lnlinear_kfeatures"):   # (the hand-over writes 4 + 2 bytes per output element)
-                hbm = np.mean([m["m"] * m["k"] * (10.0 if m["res"] else 4.0) + (6.0 if "t" in m else 2.0) * m["m"] * m["n"] for m in metas])
+            if name == "lnlinear":
+                hbm = np.mean([m["m"] * m["k"] * (10.0 if m["res"] else 4.0) + 2.0 * m["m"] * m["n"] for m in metas])
                 entry["hbm_GBs"] = round(hbm / (avg * 1e-3) / 1e9, 1)
+            elif name == "lnlinear_kfeatures":
+                # HBM-bound: x f32 (+ the pending branch output f16) in, fp32 + f16 features and the norms out (CLS rows dropped)
+                hbm = np.mean([m["m"] * m["k"] * (6.0 if m["res"] else 4.0) + (m["m"] - m["m"] // m["t"]) * (6.0 * m["n"] + 4.0) for m in metas])
+                entry.update(bound="hbm", achieved=hbm / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                             mfma_TFs=round(flops / (avg * 1e-3) / 1e12, 1))
         elif name == "layernorm":
             byts = np.mean([m["rows"] * m["d"] * (4 + m["out_bytes"] + (6 if m["res"] else 0)) for m in metas])
             entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")

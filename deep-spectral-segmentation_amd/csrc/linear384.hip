@@ -79,7 +79,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 // wave; gfx9 retires loads, LDS-DMA and stores through ONE in-order vmcnt):  Pt(0), X(0..NXS-1), Pt(1);  then after unit
 // v has been processed: ST(v) [the x write-back], X(v + NXS), and behind an odd v the residual tile Pt(v/2 + 2).
 // after(u) = instructions issued behind the younger of X(u) / Pt(u/2) when unit u is waited for = its s_waitcnt vmcnt.
-template <int NUNIT, int NXS, bool RES> struct LnSched {
+template <int NUNIT, int NXS, bool RES, bool ST = RES> struct LnSched {   // ST: the x write-back exists (not in the hand-over mode)
   static constexpr int after(int u) {
     int n = 0, px[64] = {}, pp[40] = {};
     if (RES) { pp[0] = n; n += 4; }
@@ -91,7 +91,7 @@ template <int NUNIT, int NXS, bool RES> struct LnSched {
         if (RES && pp[u >> 1] > last) last = pp[u >> 1];
         return n - (last + 4);
       }
-      if (RES) n += 4;
+      if (ST) n += 4;
       if (v + NXS < NUNIT) { px[v + NXS] = n; n += 4; }
       if (RES && (v & 1) && (v >> 1) + 2 < NUNIT / 2) { pp[(v >> 1) + 2] = n; n += 4; }
     }
@@ -229,7 +229,8 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     constexpr int NSLOT = (WS_SHARE + Cfg::PATCH_BYTES) / 4096;
     constexpr int NXS = RES ? NSLOT - 2 : NSLOT;             // x slots (K = 384: 3 / 5; K = 768: 2 / 4); 2 residual slots
     static_assert(WS_SHARE % 4096 == 0 && Cfg::PATCH_BYTES % 4096 == 0 && NXS >= 2 && NCB % 2 == 0 && NUNIT <= 48, "LN prologue layout");
-    typedef LnSched<NUNIT, NXS, RES> Sched;
+    constexpr bool XST = RES && PIPE != 2;                  // the hand-over kernel is the stream's LAST reader: x + res is used, not stored
+    typedef LnSched<NUNIT, NXS, RES, XST> Sched;
     unsigned char* const ws_share = &Ws[0][0] + wave * WS_SHARE;
     unsigned char* const patch = &Stg[wave][0];
     auto slot_ptr = [&](int i) -> unsigned char* { return i * 4096 < WS_SHARE ? ws_share + i * 4096 : patch + (i * 4096 - WS_SHARE); };
@@ -315,7 +316,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       s1[t] += u1[0] + u1[1];
       s2[t] += u2[0] + u2[1];
       asm volatile("" : "+v"(s1[t]), "+v"(s2[t]));             // ... and the moments are final HERE, not 20 units later
-      if constexpr (RES) {
+      if constexpr (XST) {
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {                       // the sums go back into the slot (same lanes, same places) ...
           *reinterpret_cast<f32x4v*>(xr + ((16u * (4 * sl + 2 * hh)) ^ fsw16)) = v0[sl];

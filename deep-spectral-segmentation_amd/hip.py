@@ -297,7 +297,7 @@ def lnlinear(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor
 def lnlinear_kfeatures(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor, aux: torch.Tensor, eps: float,
                        norm_eps: float = 1e-12, residual_planar: bool = False, out=None):
     """The hooked block's K projection from the residual stream to the hand-over, in one kernel
-    (``dss_lnlinear_kfeatures_k384``): ``x`` f32 ``[B, T, 384]`` (``+= residual`` in place), ``wg, aux`` =
+    (``dss_lnlinear_kfeatures_k384``): ``x`` f32 ``[B, T, 384]`` (read only: ``x + residual`` is used, not stored), ``wg, aux`` =
     ``lnlinear_prepare`` of the K rows of the qkv weight -> ``(k32 [B, T-1, 384] f32, k16 the same in f16, rnorm [B, T-1])``
     with the CLS row dropped - what ``layernorm`` + a library GEMM + ``kfeatures_finalize`` produce in three passes.
     ``out``: the three destinations, as for ``kfeatures_finalize``."""

@@ -117,7 +117,8 @@ int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps,
  *   k32   [M / T * (T - 1), 384] f32  the features (fp32 accumulators, never rounded),
  *   k16   the same rounded to f16, and
  *   rnorm [M / T * (T - 1)]  = 1 / max(|k16 row|_2, norm_eps)   (the norm of the ROUNDED row: w_ii = 1 exactly);
- * CLS rows are computed and dropped.  x [M, 384] f32 is updated in place (x += residual) as in dss_lnlinear_k384.
+ * CLS rows are computed and dropped.  x [M, 384] f32 is READ ONLY here (the hooked block is the stream's last reader: x + residual
+ * is used and not stored - the one difference from dss_lnlinear_k384's prologue).
  * f16 operands only; 64 < T, M * T < 2^32.  Replaces dss_layernorm_fwd + a library GEMM + dss_kfeatures_finalize. */
 int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
                                 float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream);
