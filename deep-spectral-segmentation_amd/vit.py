@@ -277,9 +277,11 @@ class DinoViT:
         if self.k_proj_fp32:  # all-fp32 K projection (3x slower GEMM; same operand rounding as nowhere else)
             h32 = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, torch.float32, residual=pending)
             k = F.linear(h32, blk["k_w32"], blk["k_b32"])
-        elif _finalize and "k_wg" in blk and t > 64:
-            # residual add + norm1 + K projection + the whole hand-over in one kernel (fp32 features straight from the accumulators)
-            return hip.lnlinear_kfeatures(x, pending, blk["k_wg"], blk["k_aux"], LN_EPS, out=_out)
+        elif "k_wg" in blk and t > 64:
+            # residual add + norm1 + K projection + the whole hand-over in one kernel (fp32 features straight from the
+            # accumulators); a caller that only wants the features (`extract_features`) drops the other two outputs
+            res = hip.lnlinear_kfeatures(x, pending, blk["k_wg"], blk["k_aux"], LN_EPS, out=_out)
+            return res if _finalize else res[0]
         else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
             hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
             with hip._timed("library_gemm", m=b * t, n=d, k=d, what="k_proj"):
