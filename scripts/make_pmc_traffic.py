@@ -27,6 +27,7 @@ KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name (or a pr
     # one template, two bench keys
     "linear_kres": lambda n: _kres_lnm(n) == 0,
     "lnlinear": lambda n: _kres_lnm(n) in (1, 2),
+    "lnlinear_kfeatures": "kfeat_kres_kernel",
     "attention": "attn_fwd",
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_",
