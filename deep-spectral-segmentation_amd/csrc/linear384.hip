@@ -36,8 +36,16 @@
 //     f16: two units) in the wave's transpose patch; the lane reads its fragment-shaped share, adds, accumulates
 //     pivot-shifted first and second moments of ITS two rows (a lane owns whole half rows: no butterfly, one lane^32
 //     exchange at the end), packs the raw sum into the resident A fragments, writes the f32 sums back into the slot and
-//     stores them as full lines; when the statistics are complete the fragments are normalised in place
-//     ((a - mean) rstd: gamma and beta are folded into W and bias by the caller).
+//     stores them as full lines.  The fragments STAY raw (f16(x): one rounding): (x - mean) rstd never exists - the mean and
+//     sigma corrections are one fp32 MFMA k-step per chunk against the caller's table aux[col] = (-sum_k Wg, b') and the
+//     epilogue multiplies by rstd (gamma and beta are folded into W and the table by dss_lnlinear_prepare).
+//   * round 4: the hooked block's K projection is the same body in a hand-over mode (kfeat_kres_kernel,
+//     dss_lnlinear_kfeatures_k384; see KfOut): read-only prologue, fp32 features from the accumulators + f16 copy + inverse
+//     row norms, CLS rows dropped.
+//   * K = 384 runs FOUR waves per workgroup and two workgroups per CU (see LinCfg); K = 768 eight waves, one workgroup.
+//   * lab builds (results documented in profiles/r0N_linear_lab.txt, none shipped): DSS_LIN_TIMELINE, DSS_LIN_ABL,
+//     DSS_LIN_PLAIN_PREFETCH, DSS_LIN_LAB_RT1 (one tile per wave, three waves per SIMD), DSS_LIN_LAB_PIPE (one wave per SIMD,
+//     the epilogue inside the next chunk's MFMAs), DSS_LIN_LAB_STAGGER, DSS_GELU_SCALAR (kres.h).
 #include "common.h"
 #include "kres.h"
 #include <utility>
