@@ -60,9 +60,15 @@ __global__ void preprocess_patchify_kernel(const uint8_t* __restrict__ img, T* _
 // Fast path for P % 8 == 0 (every DINO ViT): one thread = 8 consecutive pixels of one patch row, all 3 channels:
 // 24 contiguous input bytes -> three 16-byte stores (8 halves / floats of one (c, py) segment).  The index
 // arithmetic (the expensive part of the generic kernel) is paid once per 24 elements.
+// The transform has 3 x 256 possible results: every workgroup tabulates them once (the two IEEE divisions of
+// transform_px are ~20 instructions per element, 480 of the kernel's 960 per chunk - it ran at 3 TB/s, issue-bound) and
+// an element becomes one LDS read of the SAME value, already rounded to T.
 template <class T>
-__global__ void preprocess_patchify8_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, int H, int W,
-                                            int P, int Hp, int Wp, long total_chunks) {
+__global__ __launch_bounds__(256) void preprocess_patchify8_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, int H, int W,
+                                                                   int P, int Hp, int Wp, long total_chunks) {
+  __shared__ T lut[3][256];
+  for (int e = threadIdx.x; e < 768; e += blockDim.x) lut[e >> 8][e & 255] = from_f32<T>(transform_px((uint8_t)(e & 255), e >> 8));
+  __syncthreads();
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   const int cpr = P >> 3;                 // chunks per patch row
@@ -85,7 +91,7 @@ __global__ void preprocess_patchify8_kernel(const uint8_t* __restrict__ img, T* 
     for (int c = 0; c < 3; ++c) {
       T v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = from_f32<T>(transform_px(px[3 * k + c], c));
+      for (int k = 0; k < 8; ++k) v[k] = lut[c][px[3 * k + c]];
       T* d = dst + (long)c * P * P;
 #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = v[k];
