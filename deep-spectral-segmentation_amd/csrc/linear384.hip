@@ -203,10 +203,15 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       rowoff[q] = (unsigned)min(rloc + rowp, mrem - 1) * (unsigned)(LK * 2) + 16u * ch;
 #endif
     }
-    const unsigned char* pw = &Stg[wave][0];
+    // Two landing buffers - the wave's patch and its share of the (still idle) W double buffer - so that round rd + 1 is in
+    // flight while round rd's fragments are read: a round used to cost a full DMA round trip (issue, vmcnt(0), read), six
+    // (twelve) of them back to back were 25 % of the N = 384 kernel.
+    constexpr int WS_SHARE = 2 * Cfg::CHUNK_BYTES / LWAVES;
+    static_assert(WS_SHARE >= NPIECE * 1024, "the wave's share of the W buffers holds one 64-column round");
+    const unsigned char* pbuf[2] = {&Stg[wave][0], &Ws[0][0] + wave * WS_SHARE};
+    const unsigned pdst2[2] = {pdst, (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds3_t)(&Ws[0][0] + wave * WS_SHARE))};
     const unsigned fsw = (unsigned)((li >> 1) & 7);
-#pragma unroll
-    for (int rd = 0; rd < NROUND; ++rd) {
+    auto issue_round = [&](int rd) {
 #pragma unroll
       for (int q = 0; q < NPIECE; ++q) {
         unsigned keep;
@@ -217,16 +222,25 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
 #endif
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                      "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(pdst + 1024u * q), "v"(off), "s"(asrc) : "memory");
+                     : "=&s"(keep) : "s"(pdst2[rd & 1] + 1024u * q), "v"(off), "s"(asrc) : "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    issue_round(0);
+    if (NROUND > 1) issue_round(1);
+    static_for<NROUND>([&](auto rc) {
+      constexpr int rd = decltype(rc)::value;
+      if constexpr (rd + 1 < NROUND) wait_vmcnt<NPIECE>();    // round rd has landed, rd + 1 may still be in flight
+      else wait_vmcnt<0>();
+      const unsigned char* pw = pbuf[rd & 1];
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl)
           a[t][4 * rd + sl] = *reinterpret_cast<const V8*>(pw + (32 * t + li) * 128 + ((((unsigned)(2 * sl + hh)) ^ fsw) << 4));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers before the next round lands
-    }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers before the buffer is reused
+      if constexpr (rd + 2 < NROUND) issue_round(rd + 2);
+    });
+    __syncthreads();                                           // the W double buffer returns to its owner
   } else {
     // ---- LayerNorm prologue: x (+= res) -> statistics -> normalised A fragments (see the file header) ---------------------
     typedef __attribute__((address_space(3))) void* lds3_t;
