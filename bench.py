@@ -99,9 +99,6 @@ def parse():
                     help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
     ap.add_argument("--no-fuse-ln", action="store_true",
                     help="A/B arm: standalone residual + LayerNorm passes instead of the fused dss_lnlinear_* prologue")
-    ap.add_argument("--gram-dma", action="store_true",
-                    help="A/B arm: the D = 384 affinity build on gram_f16_dma_kernel (dss_affinity_f16_u16) instead of the "
-                         "K-resident kernel's affinity mode (dss_affinity_f16_u16_k384)")
     ap.add_argument("--no-fuse-k", action="store_true",
                     help="A/B arm: the hooked block's K projection as LayerNorm + library GEMM + dss_kfeatures_finalize "
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
@@ -501,7 +498,6 @@ def main():
         raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
                          f"(or run `python bench.py --gpus {a.gpus}` alone: it spawns its own ranks)")
     backend = torch.distributed.get_backend() if world > 1 else None
-    hip.GRAM_KRES = not a.gram_dma
     if world > 1 and backend != "nccl" and not os.environ.get("DSS_DIST_BACKEND"):
         raise SystemExit(f"[bench] multi-GPU runs must use the nccl (= RCCL) backend, got {backend}")
     dev = distributed.local_device()
@@ -650,10 +646,8 @@ def main():
                        "images_per_step": a.batch, "images_total": n_images,
                        "vit_batch": a.vit_batch, "patches": n_patches, "weights": "synthetic trunc_normal(0.02) seed 0",
                        "vit_operands": "f16" if dtype == torch.float16 else "bf16", "accumulate": "fp32",
-                       "affinity": {"fused": "f16 features + inverse norms from the K projection's own epilogue -> "
-                                             + ("f16-operand Gram on the K-resident kernel (256 rows of an image resident, its rows "
-                                                "streamed as the weight, fp32 accumulate)" if dim == 384 and not a.gram_dma else
-                                                "f16-operand Gram (fp32 accumulate, 256x128 tiles, LDS-DMA panels)") + " -> u16 W"
+                       "affinity": {"fused": "f16 features + inverse norms from the K projection's hand-over kernel -> "
+                                             "f16-operand Gram (fp32 accumulate, 256x128 tiles, LDS-DMA panels) -> u16 W"
                                              if a.w_dtype == "u16" else "split-f16 (hi+lo f16 terms, fp32 accumulate)",
                                     "split": "split-f16 (hi+lo f16 terms, fp32 accumulate)",
                                     "fp32": "exact fp32 MFMA"}[a.affinity],

@@ -140,16 +140,11 @@ __device__ int dss_lin_stagger[2];
 #endif
 // PIPE (lab, DSS_LIN_LAB_PIPE): ONE wave per SIMD owns all 512 registers and overlaps the epilogue of chunk c - 1 with the MFMAs
 // of chunk c (see the chunk loop).
-// MODE 3 (patch affinity, dss_affinity_f16_u16_k384; affinity.hip's header has the arithmetic): the SAME kernel computes an image's
-// Gram matrix - A = 256 of its f16 feature rows (resident), `W` = all of its feature rows streamed in 32-row chunks, workgroup =
-// (image, row block), M = patches per image, N = the padded order ldw - and the epilogue turns <x_i, x_j> into
-// round(65535 relu(<x_i, x_j> r_i r_j)) in the packed 64 x 64 upper-triangle tiles the eigensolver reads (aux = the inverse norms
-// of the image, C = its packed W; a wave owns one 64-row strip = one tile row and starts at its diagonal tile).
 // MODE 2 (K-feature hand-over, dss_lnlinear_kfeatures_k384): the output of the LAST block's K projection leaves as what the
 // caller and the affinity build need - token rows b * Tn + t, t >= 1, go to row b * (Tn - 1) + t - 1 of k32 (fp32, straight
 // from the accumulators: 16-byte pieces, a 32-column chunk of a row is one 128-byte line written by one wave), of C = k16
 // (through the transpose patch, as every other output) and rnorm = 1 / max(|k16 row|, eps); CLS rows are computed and dropped.
-struct KfOut { float* k32; float* rnorm; int Tn; float eps; size_t wstride; };
+struct KfOut { float* k32; float* rnorm; int Tn; float eps; };
 
 template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE>
 __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float* __restrict__ X,
@@ -166,16 +161,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
-  int rowblk = blockIdx.x;                                 // which LBM-row block of the row space this workgroup owns
-  if constexpr (PIPE == 3) {                               // (image, row block): rows, columns, norms and output of ONE image
-    const int nrb = (M + LBM - 1) / LBM, img = blockIdx.x / nrb;
-    rowblk = blockIdx.x - img * nrb;
-    A += (size_t)img * M * LK;
-    W = A;
-    aux += (size_t)img * M;
-    C = reinterpret_cast<T*>(reinterpret_cast<unsigned short*>(C) + (size_t)img * kf.wstride);
-  }
-  const int mrem = M - rowblk * LBM;                       // rows of this workgroup that exist (> 0)
+  const int mrem = M - blockIdx.x * LBM;                   // rows of this workgroup that exist (> 0)
   const int rloc = wave * Cfg::ROWS_WAVE;                  // this wave's first row inside the workgroup
   const bool block_full = mrem >= LBM;
 
@@ -200,7 +186,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   float am[RT];                                            // LNM != 0: A side of the correction k-step (mean | sigma), per row tile
   if constexpr (LNM == 0) {
     typedef __attribute__((address_space(3))) void* lds3_t;
-    const unsigned long long abase = (unsigned long long)(A + (long)rowblk * LBM * LK);
+    const unsigned long long abase = (unsigned long long)(A + (long)blockIdx.x * LBM * LK);
     const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)abase), ahi = __builtin_amdgcn_readfirstlane((unsigned)(abase >> 32));
     const unsigned char* asrc = reinterpret_cast<const unsigned char*>(((unsigned long long)ahi << 32) | alo);
     const unsigned pdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds3_t)(&Stg[wave][0]));
@@ -270,7 +256,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     unsigned char* const ws_share = &Ws[0][0] + wave * WS_SHARE;
     unsigned char* const patch = &Stg[wave][0];
     auto slot_ptr = [&](int i) -> unsigned char* { return i * 4096 < WS_SHARE ? ws_share + i * 4096 : patch + (i * 4096 - WS_SHARE); };
-    const size_t row0 = (size_t)rowblk * LBM;
+    const size_t row0 = (size_t)blockIdx.x * LBM;
     const unsigned char* const xblk = reinterpret_cast<const unsigned char*>(X) + row0 * (size_t)(LK * 4);
     const unsigned char* const rblk = reinterpret_cast<const unsigned char*>(R) + row0 * (size_t)r_ld * 2;
     const unsigned r_ldb = (unsigned)r_ld * 2u;
@@ -398,11 +384,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     const unsigned dst0 = (unsigned)(size_t)(lds_ptr_t)(&Ws[c & 1][wave * NST * 1024]);
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
-      unsigned off = gsrc0 + 32u * j;
-      if constexpr (PIPE == 3) {                             // rows past the image: the last row again (finite; their columns get r_j = 0)
-        src = reinterpret_cast<const unsigned char*>(W);
-        off = (unsigned)min(c * LBN + li, M - 1) * (unsigned)(LK * 2) + 16u * hh + 32u * (wave * NST + j);
-      }
+      const unsigned off = gsrc0 + 32u * j;
       const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + 1024u * j);
       // inline asm, not the builtin: the compiler's alias model would put s_waitcnt vmcnt(0) in front of the very
       // next ds_read and expose the whole L2 latency; the consumers sit behind wait_vm() + a barrier
@@ -428,7 +410,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
   // Ragged workgroups predicate their stores (unknown count): they wait for everything.
   auto wait_dma = [&](int c_stored) {
-    if (PIPE != 2 && (block_full || PIPE == 3) && (c_stored & 1)) {   // (the hand-over mode predicates its stores per row: unknown counts)
+    if (PIPE != 2 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
       if (Cfg::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -439,8 +421,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // bias of this lane's column in the chunk, fetched one chunk ahead (a plain load: hipcc waits for it at its first use,
   // the START of the next chunk's MFMA phase, right behind wait_dma + barrier where nothing younger is in flight)
   T bias_next = from_f32<T>(0.f);
-  if constexpr (LNM == 0 && PIPE != 3) bias_next = bias[li];
-  float rnj = 0.f, rnj_next = 0.f;                         // mode 3: inverse norm of column li of the current / next chunk
+  if constexpr (LNM == 0) bias_next = bias[li];
   (void)LTHREADS;
 
   // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
@@ -451,15 +432,9 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // row-major C[M][N]: row stride 2N bytes, 64-column group p at byte 128 p of the row.  planar C[N/64][M][64]:
   // row stride 128 bytes, group p is a plane of 128 M bytes - a wave's 64 x 64 tile is 8 KB CONTIGUOUS (measured:
   // contiguous runs cost ~35 us of write-back per 531 MB where row-major full lines cost ~80 us)
-  const size_t ldc = (planar || PIPE == 3) ? 128 : (size_t)(N * 2);
-  const size_t gstride = PIPE == 3 ? 8192 : planar ? (size_t)M * 128 : 128;
-  unsigned char* cblk = reinterpret_cast<unsigned char*>(C) + (size_t)rowblk * LBM * ldc;
-  // mode 3: this wave's 64-row strip is tile row `strip` of the packed upper triangle; tile (strip, tj) = 8 KB, consecutive in tj
-  const int strip = PIPE == 3 ? __builtin_amdgcn_readfirstlane((rowblk * LBM + rloc) >> 6) : 0;
-  if constexpr (PIPE == 3) {
-    const int nt = N >> 6;
-    cblk = reinterpret_cast<unsigned char*>(C) + ((size_t)(strip * nt - strip * (strip - 1) / 2) - (size_t)strip) * 8192;
-  }
+  const size_t ldc = planar ? 128 : (size_t)(N * 2);
+  const size_t gstride = planar ? (size_t)M * 128 : 128;
+  unsigned char* cblk = reinterpret_cast<unsigned char*>(C) + (size_t)blockIdx.x * LBM * ldc;
 
   f32x16 acc0, acc1;   // RT = 2: row tiles 0 / 1.  RT = 1: even / odd k-steps of the one row tile (two MFMA chains)
 
@@ -486,10 +461,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
 #endif
     const float bcol = to_f32<T>(bias_next);
     float wcorr = 0.f;
-    if constexpr (PIPE == 3) {
-      rnj = rnj_next;                                        // r_j of THIS chunk's column li; the next chunk's is requested here
-      rnj_next = (c + 1) * LBN + li < M ? aux[(c + 1) * LBN + li] : 0.f;
-    } else if constexpr (LNM == 0) {
+    if constexpr (LNM == 0) {
       if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
     } else {
       // aux[col] = (-sw, b) of THIS chunk, needed by its last MFMA: requested here, awaited there by count (the NST pieces of the
@@ -522,9 +494,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);
       }
     });
-    if constexpr (PIPE == 3) {
-      (void)bcol;
-    } else if constexpr (LNM == 0) {
+    if constexpr (LNM == 0) {
       V8 fb, a_one;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -553,7 +523,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // output row of accumulator row (tile t, lane row l31), rebuilt where it is used (a register pair held through the MFMA
   // phases otherwise): -1 = CLS or past M
   auto kf_row = [&](int t, unsigned l31) -> int {           // (one division: rows l31 and l31 + 32 straddle at most one image boundary)
-    const unsigned gr0 = (unsigned)rowblk * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + l31, gr = gr0 + 32 * t;
+    const unsigned gr0 = (unsigned)blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + l31, gr = gr0 + 32 * t;
     const unsigned b0 = __umulhi(gr0, kmagic);
     const unsigned cls0 = b0 * (unsigned)kf.Tn, cls1 = cls0 + (unsigned)kf.Tn;
     return ((int)gr < M && gr != cls0 && gr != cls1) ? (int)(gr - b0 - 1u - (gr >= cls1 ? 1u : 0u)) : -1;
@@ -604,38 +574,6 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     asm volatile("" :: "v"(acc0), "v"(acc1));
     return;
 #endif
-    if constexpr (PIPE == 3) {
-      // w = <x_i, x_j> r_i r_j -> round(65535 relu(w)) (v_cvt_pknorm_u16: clamp to [0, 1] and round in one instruction), the
-      // same arithmetic as gram_f16_dma_kernel.  r_i: am[t] (this lane's rows).  r_j: lane li holds column li's; a lane's 16
-      // columns (r & 3) + 8 (r >> 2) + 4 hh come over the LDS crossbar (ds_bpermute: no LDS storage, the kernel has none).
-      typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
-      typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-      const unsigned half3 = 64u * (c & 1);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float sj[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          sj[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute((int)(4u * (8u * g + 4u * ehh + i)), (int)__float_as_uint(rnj)));
-        unsigned char* wp = stg_w + ((half3 + 16 * g) ^ stg_x);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (t == 0 ? acc0[4 * g + i] : acc1[4 * g + i]) * am[t] * sj[i];
-          const u16x2v q0 = __builtin_amdgcn_cvt_pknorm_u16(v[0], v[1]), q1 = __builtin_amdgcn_cvt_pknorm_u16(v[2], v[3]);
-          *reinterpret_cast<u32x2v*>(wp + 4096 * t) = u32x2v{__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-        }
-      }
-      if (!(c & 1)) return;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      unsigned char* cw3 = cblk + (size_t)(c >> 1) * gstride;   // tile (strip, c >> 1): 64 rows x 128 B, every row written
-#pragma unroll
-      for (int i = 0; i < Cfg::NSTORE; ++i)
-        __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
-                                    reinterpret_cast<V8*>(cw3 + (unsigned)((rq + 8 * i) * 128 + 16 * pq)));
-      return;
-    }
     if constexpr (PIPE == 2) {
       // (uniform base in SGPRs + 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic per lane)
       typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -665,7 +603,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read (other lanes' data)
       unsigned char* const k16c = reinterpret_cast<unsigned char*>(C) + (size_t)((c >> 1) * 128);          // uniform
       // rows rq + 8 i of this wave's 64: at most ONE image boundary among them (Tn > 64, host-checked) - one division
-      const unsigned gr0 = (unsigned)rowblk * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + rq;
+      const unsigned gr0 = (unsigned)blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + rq;
       const unsigned b0 = __umulhi(gr0, kmagic);
       const unsigned cls0 = b0 * (unsigned)kf.Tn, cls1 = cls0 + (unsigned)kf.Tn;      // the CLS rows of image b0 and b0 + 1
       const unsigned off0 = (gr0 - b0 - 1u) * (unsigned)(LK * 2) + 16u * (unsigned)pq;
@@ -885,35 +823,16 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     return;
   }
 #endif
-  // mode 3: the workgroup's first strip starts at its diagonal tile = chunk 2 strip0 (upper triangle); a wave whose own strip starts
-  // later stages its share of the chunks before that and computes nothing (strips past the padded order have no tile at all)
-  const int c_begin = PIPE == 3 ? 2 * ((rowblk * LBM) >> 6) : 0;
-  const int c_first = PIPE == 3 ? 2 * strip : 0;
-  if constexpr (PIPE == 3) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      const int row = rowblk * LBM + rloc + 32 * t + li;
-      am[t] = row < M ? aux[row] : 0.f;                    // r_i of this lane's rows (0 past the image: zero rows in the tile)
-    }
-    rnj_next = c_begin * LBN + li < M ? aux[c_begin * LBN + li] : 0.f;
-  }
-  stage(c_begin);
+  stage(0);
   wait_vm();
   __syncthreads();
   DSS_TL_MARK(0)
-  for (int c = c_begin; c < nchunks; ++c) {
-    const bool mine = PIPE != 3 || c >= c_first;
-    if (mine) {
-      mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
-      DSS_TL_MARK(1)
-      epilogue(c);
-    } else {
-      rnj_next = (c + 1) * LBN + li < M ? aux[(c + 1) * LBN + li] : 0.f;
-      if (c + 1 < nchunks) stage(c + 1);
-    }
+  for (int c = 0; c < nchunks; ++c) {
+    mfma_phase(c, c + 1 < nchunks ? c + 1 : -1);
+    DSS_TL_MARK(1)
+    epilogue(c);
     DSS_TL_MARK(2)
-    if (mine) wait_dma(c);
-    else wait_vm();
+    wait_dma(c);
     phase_barrier();
     DSS_TL_MARK(3)
   }
@@ -927,14 +846,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE == 1 && RT == 2) || NW == 8 ? 1 : 2)
                                                                  const T* __restrict__ W,
                                                                  const T* __restrict__ bias, const float* __restrict__ aux,
                                                                  T* __restrict__ C, int M, int N, int planar) {
-  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f, 0});
-}
-
-// The K = 384 kernel as the patch-affinity build (mode 3): grid = images x ceil(Npts / 256) row blocks.
-__global__ __launch_bounds__(256, 2) void gram_kres_kernel(const f16* __restrict__ feats, const float* __restrict__ rnorm,
-                                                           unsigned short* __restrict__ Wout, int Npts, int ldw, size_t wstride) {
-  linear_kres_body<f16, false, 24, 2, 4, 0, 3>(feats, nullptr, nullptr, 0, 0, 0.f, feats, nullptr, rnorm, reinterpret_cast<f16*>(Wout), Npts, ldw, 0,
-                                               KfOut{nullptr, nullptr, 0, 0.f, wstride});
+  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f});
 }
 
 // The K = 384 kernel in its hand-over mode (see KfOut): N = 384 output columns, no bias pointer (it rides in aux).
@@ -942,7 +854,7 @@ template <class T, int LNM>
 __global__ __launch_bounds__(256, 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                             const T* __restrict__ W, const float* __restrict__ aux, T* __restrict__ k16,
                                                             float* __restrict__ k32, float* __restrict__ rnorm, int M, int Tn, float norm_eps) {
-  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps, 0});
+  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps});
 }
 
 // One wave per output column: Wg[n][k] = T(W[n][k] gamma[k]);  aux[n] = (-sum_k float(Wg[n][k]), bias[n] + sum_k W[n][k] beta[k])
@@ -1054,19 +966,6 @@ extern "C" int dss_lnlinear_k384(float* x, const void* residual, int res_layout,
                                  void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(x, "dss_lnlinear_k384: null pointer");
   return dss::linear_kres<24, 2, 4>("dss_lnlinear_k384", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
-}
-
-extern "C" int dss_affinity_f16_u16_k384(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, void* stream) {
-  DSS_REQUIRE(feats16 && rnorm && W, "dss_affinity_f16_u16_k384: null pointer");
-  DSS_REQUIRE(B > 0 && N > 0, "dss_affinity_f16_u16_k384: bad shape B=%d N=%d", B, N);
-  const int ldw = dss_affinity_ld(N);
-  DSS_REQUIRE((long)N * 768 < 4294967296L, "dss_affinity_f16_u16_k384: one image's features exceed the DMA's 32-bit offsets");
-  const long nblocks = (long)B * dss::ceil_div(N, dss::LinCfg<24, 2, 4>::ROWS);
-  DSS_REQUIRE(nblocks < 2147483647L, "dss_affinity_f16_u16_k384: too many blocks (%ld)", nblocks);
-  hipLaunchKernelGGL(dss::gram_kres_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const dss::f16*)feats16, rnorm,
-                     W, N, ldw, dss_affinity_elems(N));
-  DSS_CHECK_LAUNCH("dss_affinity_f16_u16_k384");
-  return DSS_OK;
 }
 
 extern "C" int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,

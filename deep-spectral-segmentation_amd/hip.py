@@ -50,7 +50,6 @@ SYMBOLS = {
     "dss_affinity_split_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "dss_affinity_fused_u16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_f16_u16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "dss_affinity_f16_u16_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dss_kfeatures_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p]),
     "dss_eigs_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -79,7 +78,6 @@ _lib: Optional[ctypes.CDLL] = None
 # launches per step is not a measurement any more but a load) - and count every launch in TIMERS["_launches"][name].
 TIMERS: Optional[dict] = None
 TIMER_SAMPLE = 1
-GRAM_KRES = True   # D = 384: the affinity build on the K-resident kernel (bench.py --gram-dma sets the A/B arm)
 TIMER_ALWAYS = ("laplacian_eigs", "affinity", "kfeatures_finalize", "lnlinear_kfeatures", "layernorm")   # a handful of launches per step: all timed
 
 
@@ -437,24 +435,16 @@ def affinity_fused_u16(feats: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     return w
 
 
-def affinity_f16_u16(feats16: torch.Tensor, rnorm: torch.Tensor, kres: Optional[bool] = None) -> torch.Tensor:
-    """f16 ``[B, N, D]`` features + inverse row norms ``[B, N]`` (the K projection's hand-over) -> the packed 16-bit W of
-    ``affinity_fused_u16``.  D = 384: ``dss_affinity_f16_u16_k384`` - the K-resident Linear kernel with the image's own
-    feature rows as its weight and the affinity arithmetic as its epilogue (``kres=False``: the A/B arm); any D:
-    ``dss_affinity_f16_u16`` (256 x 128 tiles, both panels by LDS-DMA)."""
+def affinity_f16_u16(feats16: torch.Tensor, rnorm: torch.Tensor) -> torch.Tensor:
+    """f16 ``[B, N, D]`` features + inverse row norms ``[B, N]`` (``kfeatures_finalize``) -> the packed 16-bit W of
+    ``affinity_fused_u16`` (``dss_affinity_f16_u16``: 256 x 128 tiles, panels by LDS-DMA)."""
     assert feats16.dtype == torch.float16 and feats16.dim() == 3 and rnorm.dtype == torch.float32
     b, n, d = feats16.shape
     assert rnorm.numel() == b * n
-    if kres is None:
-        kres = GRAM_KRES
     w = torch.empty((b, affinity_elems(n)), dtype=torch.int16, device=feats16.device)
-    with _timed("affinity", b=b, n=n, d=d, w_bytes=2, f16_in=True, kres=bool(kres and d == 384)):
-        if kres and d == 384:
-            _check(load_library().dss_affinity_f16_u16_k384(_dev(feats16, "feats16"), _dev(rnorm, "rnorm"), _dev(w, "W"), b, n,
-                                                            _stream()), "dss_affinity_f16_u16_k384")
-        else:
-            _check(load_library().dss_affinity_f16_u16(_dev(feats16, "feats16"), _dev(rnorm, "rnorm"), _dev(w, "W"), b, n, d,
-                                                       _stream()), "dss_affinity_f16_u16")
+    with _timed("affinity", b=b, n=n, d=d, w_bytes=2, f16_in=True):
+        _check(load_library().dss_affinity_f16_u16(_dev(feats16, "feats16"), _dev(rnorm, "rnorm"), _dev(w, "W"), b, n, d,
+                                                   _stream()), "dss_affinity_f16_u16")
     return w
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DSS_ABI_VERSION 6
+#define DSS_ABI_VERSION 5
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -168,12 +168,6 @@ int dss_affinity_fused_u16(const float* feats, uint16_t* W, int B, int N, int D,
  * out.  256 x 128 block tiles, panels by LDS-DMA (affinity.hip: gram_f16_dma_kernel).  Algorithmic bytes per image:
  * 2 N D + 4 N in, 2 * dss_affinity_elems(N) out.  D % 32 == 0.  extract/extract.py:148,191-193. */
 int dss_affinity_f16_u16(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, int D, void* stream);
-/* dss_affinity_f16_u16 for D = 384 on the K-resident Linear kernel (linear384.hip, mode 3): a workgroup keeps 256 feature rows
- * of an image as MFMA operands in registers, streams all of the image's rows through LDS in 32-row chunks as the "weight",
- * and its epilogue is the affinity arithmetic - <x_i, x_j> r_i r_j, relu, round(65535 w) - written as full 128-byte rows of
- * the packed tiles; a wave owns one tile row and starts at its diagonal tile.  Same inputs, output layout, value definition
- * and algorithmic bytes as dss_affinity_f16_u16 (the fp32 sums may differ in the last bit: different k order inside the MFMA). */
-int dss_affinity_f16_u16_k384(const void* feats16, const float* rnorm, uint16_t* W, int B, int N, void* stream);
 
 /* a7/a10 hand-over between the two stages when they run back to back in HBM (extract/extract.py:96-98,148): the raw fp32
  * output of the last block's K projection kproj [B, T, D] (token 0 = CLS; + bias [D] unless NULL) -> k32 [B, T-1, D] fp32

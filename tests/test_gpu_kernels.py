@@ -478,8 +478,7 @@ def test_affinity_matches_fp64(b, n, d):
 
 
 @pytest.mark.parametrize("b,n,d", [(2, 900, 384), (1, 713, 384), (1, 16, 32), (1, 65, 32), (3, 129, 768), (9, 300, 384),
-                                    (1, 3600, 768), (1, 6400, 768), (1, 40, 384), (2, 64, 384), (1, 257, 384), (1, 1600, 384),
-                                    (5, 196, 384)])
+                                    (1, 3600, 768), (1, 6400, 768)])
 def test_affinity_from_f16_handover(b, n, d):
     """The pipeline's affinity build: `kfeatures_finalize` (K-projection output + bias -> fp32 features without the CLS
     row, their f16 copy, inverse norms of the ROUNDED rows) followed by `affinity_f16_u16` (256 x 256 tiles, LDS-DMA
@@ -506,10 +505,6 @@ def test_affinity_from_f16_handover(b, n, d):
     assert wq.min().item() >= 0.0 and wq.max().item() <= 1.0
     assert abs(torch.diagonal(wq[:, :n, :n], dim1=1, dim2=2).min().item() - 1.0) < 2e-5
     assert (wq - wq.transpose(1, 2)).abs().max().item() <= 1.01 / 65535
-    if d == 384:   # D = 384 ran on the K-resident kernel's affinity mode: the tile kernel on the same inputs is at most one step away
-        wd = hip.affinity_to_dense(hip.affinity_f16_u16(k16, rn, kres=False), n).cpu()
-        assert (wq - wd).abs().max().item() <= 1.01 / 65535
-        assert (wq != wd).float().mean().item() <= 0.02
     if d >= 256:   # the same operands as the one-kernel build from fp32 (it rounds to f16 itself): at most one step apart
         wf = hip.affinity_to_dense(hip.affinity_fused_u16(k32), n).cpu()
         assert (wq - wf).abs().max().item() <= 2.01 / 65535
