@@ -1,7 +1,11 @@
-// linear_pipe_lab.hip - can ONE wave hide fc1's GELU under its own next chunk's MFMAs?  K = 384, one 32-row tile per wave
-// (96 operand registers), two accumulator sets, the epilogue of chunk c - 1 scheduled into the MFMA chain of chunk c
-// (sched_group_barrier; -DDSS_LIN_LAB_PIPE=<VALU per MFMA>), against the product's kernel on the same inputs.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDSS_LIN_LAB_PIPE=10 scripts/probes/linear_pipe_lab.hip deep-spectral-segmentation_amd/csrc/lib.hip -o scripts/probes/linear_pipe_lab
+// linear_pipe_lab.hip - can ONE wave hide a chunk's epilogue (fc1's GELU) under its own next chunk's MFMAs?  K = 384, the lab build
+// of linear384.hip (-DDSS_LIN_LAB_PIPE): one workgroup of four waves per CU (one wave per SIMD, 512 registers: operand fragments
+// in the accumulation registers unless -DDSS_LIN_LAB_PIPE_NO_AGPR), two accumulator sets, the epilogue of chunk c - 1 in ten stages
+// behind the MFMAs of chunk c, against the product's kernel on the same inputs, product and lab alternating three times.
+// Answer (profiles/r04_linear_lab.txt item 8): +8 % SLOWER for fc1 + GELU, +17 % plain.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDSS_LIN_LAB_PIPE=230 -DDSS_LIN_LAB_PIPE_RT=2 -DDSS_LIN_LAB_PIPE_PF=3
+//        scripts/probes/linear_pipe_lab.hip deep-spectral-segmentation_amd/csrc/lib.hip -o scripts/probes/linear_pipe_lab_r2p3n0
+//        (DSS_LIN_LAB_PIPE's value is only printed; _RT = row tiles per wave, _PF = W fragments read ahead)
 #include "../../deep-spectral-segmentation_amd/csrc/linear384.hip"
 #include <cstdio>
 #include <cstdlib>
