@@ -99,6 +99,8 @@ def parse():
                     help="DinoViT(linear_kres=...): 0 library GEMMs only, 1 K-resident qkv/proj, 2 (default) + fc1+GELU")
     ap.add_argument("--no-fuse-ln", action="store_true",
                     help="A/B arm: standalone residual + LayerNorm passes instead of the fused dss_lnlinear_* prologue")
+    ap.add_argument("--no-fuse-pe", action="store_true",
+                    help="A/B arm: patchify + library GEMM + position-embedding add instead of the one dss_patch_embed_p16 kernel")
     ap.add_argument("--no-fuse-k", action="store_true",
                     help="A/B arm: the hooked block's K projection as LayerNorm + library GEMM + dss_kfeatures_finalize "
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
@@ -338,7 +340,7 @@ def summarize_timers(timers, n_patches, dim, depth_attn, affinity_mode="fused"):
             else:  # split-f16 build (normalise + Gram): HBM-bound; 4ND in + 4ND split write/read + w_bytes*N(N+1)/2 out
                 byts = (4.0 * m["n"] * m["d"] + m.get("w_bytes", 4) / 2.0 * m["n"] * (m["n"] + 1)) * m["b"]
                 entry.update(bound="hbm", achieved=byts / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        elif name in ("linear_kres", "lnlinear", "lnlinear_kfeatures", "library_gemm"):
+        elif name in ("linear_kres", "lnlinear", "lnlinear_kfeatures", "library_gemm", "patch_embed"):
             # both pipes matter: 2*M*N*K flop on the matrix cores and M*N*2 output bytes (1.5 - 4x the input); the fused
             # residual + LayerNorm + Linear kernel additionally reads x f32 + the pending branch output and writes x back
             flops = np.mean([2.0 * m["m"] * m["n"] * m["k"] for m in metas])
@@ -510,7 +512,7 @@ def main():
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
-                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k)
+                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -662,7 +664,7 @@ def main():
             # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
             "layernorm_launches_per_forward": round(kern.get("layernorm", {}).get("launches", 0) / max(n_forwards, 1), 2),
             "library_gemm_ms_per_step": round(kern.get("library_gemm", {}).get("total_ms", 0.0) / steps_out, 3),
-            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k},
+            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k, "fuse_pe": not a.no_fuse_pe},
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
             "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
@@ -681,7 +683,7 @@ def main():
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
-                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k)
+                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

@@ -144,7 +144,12 @@ __device__ int dss_lin_stagger[2];
 // caller and the affinity build need - token rows b * Tn + t, t >= 1, go to row b * (Tn - 1) + t - 1 of k32 (fp32, straight
 // from the accumulators: 16-byte pieces, a 32-column chunk of a row is one 128-byte line written by one wave), of C = k16
 // (through the transpose patch, as every other output) and rnorm = 1 / max(|k16 row|, eps); CLS rows are computed and dropped.
-struct KfOut { float* k32; float* rnorm; int Tn; float eps; };
+// MODE 4 (patch embedding, dss_patch_embed_p16): DINO's PatchEmbed Conv2d(3, D, 16, 16) + `x = tokens + pos_embed[1:]` straight from
+// the u8 image: a lane's operand row is one 16 x 16 x 3 patch, gathered as 8-byte pieces of its 48-byte pixel rows (k order (py, px,
+// c); ToTensor / Normalize are folded into the weight and bias by the caller), the values 0..255 are exact in f16 / bf16; the
+// epilogue adds the position embedding of the patch and writes fp32 rows b (Np + 1) + n + 1 of the residual stream - no patchify
+// pass, no f16 token tensor, no position-embedding pass.  k32 = x, Tn = Np, img / pos / H / W / Wp as named.
+struct KfOut { float* k32; float* rnorm; int Tn; float eps; const unsigned char* img; const float* pos; int H, W, Wp; };
 
 template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE>
 __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float* __restrict__ X,
@@ -184,7 +189,25 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // full lines do; measured equal in time (see LinCfg), kept for the 4x fewer L2 requests.
   V8 a[RT][LKS];
   float am[RT];                                            // LNM != 0: A side of the correction k-step (mean | sigma), per row tile
-  if constexpr (LNM == 0) {
+  if constexpr (PIPE == 4) {
+    static_assert(RT == 1 && LK == 768, "one 16 x 16 x 3 patch per operand row");
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned gp = (unsigned)min((int)blockIdx.x * LBM + rloc + li, M - 1);   // this lane's patch (M = B Np of them)
+    const unsigned pb = gp / (unsigned)kf.Tn, pn = gp - pb * (unsigned)kf.Tn;
+    const unsigned py0 = (pn / (unsigned)kf.Wp) * 16u, px0 = (pn - (pn / (unsigned)kf.Wp) * (unsigned)kf.Wp) * 16u;
+    const unsigned w3 = (unsigned)kf.W * 3u;
+    const unsigned char* psrc = kf.img + ((size_t)(pb * (unsigned)kf.H + py0) * kf.W + px0) * 3;
+    static_for<LKS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;                   // k = 16 s + 8 hh .. + 8: pixel row k / 48 of the patch, byte k % 48 of it
+      constexpr int r0 = (16 * s) / 48, o0 = (16 * s) % 48, r1 = (16 * s + 8) / 48, o1 = (16 * s + 8) % 48;
+      const unsigned off = hh ? (unsigned)r1 * w3 + (unsigned)o1 : (unsigned)r0 * w3 + (unsigned)o0;
+      const u32x2v raw = *reinterpret_cast<const u32x2v*>(psrc + off);
+      V8 fr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fr[e] = from_f32<T>((float)((raw[e >> 2] >> (8 * (e & 3))) & 0xffu));
+      a[0][s] = fr;
+    });
+  } else if constexpr (LNM == 0) {
     typedef __attribute__((address_space(3))) void* lds3_t;
     const unsigned long long abase = (unsigned long long)(A + (long)blockIdx.x * LBM * LK);
     const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)abase), ahi = __builtin_amdgcn_readfirstlane((unsigned)(abase >> 32));
@@ -410,7 +433,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
   // Ragged workgroups predicate their stores (unknown count): they wait for everything.
   auto wait_dma = [&](int c_stored) {
-    if (PIPE != 2 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
+    if (PIPE != 2 && PIPE != 4 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
       if (Cfg::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -515,6 +538,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // ---- K-feature hand-over (PIPE == 2, see KfOut): this lane's two accumulator rows -> output rows, their sums of squares
   float kss[RT];
   unsigned kmagic = 0;                                     // gr / Tn = umulhi(gr, kmagic) for gr * Tn < 2^32 (host-checked)
+  if constexpr (PIPE == 4) kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
   if constexpr (PIPE == 2) {
     kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
 #pragma unroll
@@ -574,6 +598,28 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     asm volatile("" :: "v"(acc0), "v"(acc1));
     return;
 #endif
+    if constexpr (PIPE == 4) {
+      // tokens + position embedding -> fp32 rows of the residual stream, straight from the accumulators (no patch, no f16 output)
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const unsigned gp = blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + eli;
+      const unsigned pb = __umulhi(gp, kmagic);
+      const unsigned coloff = (unsigned)(c * LBN * 4) + 16u * ehh;
+      const unsigned char* posr = reinterpret_cast<const unsigned char*>(kf.pos) + (gp - pb * (unsigned)kf.Tn) * (unsigned)(N * 4) + coloff;
+      unsigned char* xr = reinterpret_cast<unsigned char*>(kf.k32) + (gp + pb + 1u) * (unsigned)(N * 4) + coloff;
+      if ((int)gp < M) {
+        f32x4v pe[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pe[g] = *reinterpret_cast<const f32x4v*>(posr + 32 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4v v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc0[4 * g + i] + acc1[4 * g + i] + pe[g][i];
+          *reinterpret_cast<f32x4v*>(xr + 32 * g) = v;
+        }
+      }
+      return;
+    }
     if constexpr (PIPE == 2) {
       // (uniform base in SGPRs + 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic per lane)
       typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -846,7 +892,16 @@ __global__ __launch_bounds__(64 * NW, (PIPE == 1 && RT == 2) || NW == 8 ? 1 : 2)
                                                                  const T* __restrict__ W,
                                                                  const T* __restrict__ bias, const float* __restrict__ aux,
                                                                  T* __restrict__ C, int M, int N, int planar) {
-  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f});
+  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, 0, 0});
+}
+
+// The K = 768 kernel as the patch embedding (mode 4): M = B Np patches, N = D.
+template <class T>
+__global__ __launch_bounds__(512, 1) void patch_embed_kres_kernel(const unsigned char* __restrict__ img, const T* __restrict__ Wp,
+                                                                  const T* __restrict__ biasp, const float* __restrict__ pos,
+                                                                  float* __restrict__ x, int M, int N, int Np, int H, int W, int Wpat) {
+  linear_kres_body<T, false, 48, 1, 8, 0, 4>(nullptr, nullptr, nullptr, 0, 0, 0.f, Wp, biasp, nullptr, nullptr, M, N, 0,
+                                             KfOut{x, nullptr, Np, 0.f, img, pos, H, W, Wpat});
 }
 
 // The K = 384 kernel in its hand-over mode (see KfOut): N = 384 output columns, no bias pointer (it rides in aux).
@@ -854,7 +909,7 @@ template <class T, int LNM>
 __global__ __launch_bounds__(256, 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                             const T* __restrict__ W, const float* __restrict__ aux, T* __restrict__ k16,
                                                             float* __restrict__ k32, float* __restrict__ rnorm, int M, int Tn, float norm_eps) {
-  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps});
+  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps, nullptr, nullptr, 0, 0, 0});
 }
 
 // One wave per output column: Wg[n][k] = T(W[n][k] gamma[k]);  aux[n] = (-sum_k float(Wg[n][k]), bias[n] + sum_k W[n][k] beta[k])
@@ -966,6 +1021,35 @@ extern "C" int dss_lnlinear_k384(float* x, const void* residual, int res_layout,
                                  void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(x, "dss_lnlinear_k384: null pointer");
   return dss::linear_kres<24, 2, 4>("dss_lnlinear_k384", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
+}
+
+extern "C" int dss_patch_embed_p16(const uint8_t* img_u8, const void* Wp, const void* biasp, const float* pos, float* x, int B, int H, int W,
+                                   int D, int dtype, void* stream) {
+  DSS_REQUIRE(img_u8 && Wp && biasp && pos && x, "dss_patch_embed_p16: null pointer");
+  DSS_REQUIRE(B > 0 && H >= 16 && W >= 16, "dss_patch_embed_p16: bad shape B=%d H=%d W=%d", B, H, W);
+  typedef dss::LinCfg<48, 1, 8> Cfg;
+  DSS_REQUIRE(D > 0 && D % (2 * dss::LBN) == 0 && D <= Cfg::MAXN, "dss_patch_embed_p16: need D %% %d == 0, D <= %d (D=%d)", 2 * dss::LBN, Cfg::MAXN, D);
+  const int Hp = H / 16, Wpat = W / 16, Np = Hp * Wpat;
+  const long M = (long)B * Np;
+  DSS_REQUIRE(M * Np < 4294967296L && (M + B) * D * 4 < 4294967296L && (long)H * W * 3 * B < (1L << 46),
+              "dss_patch_embed_p16: B=%d x %d patches exceeds the 32-bit row arithmetic of the epilogue", B, Np);
+  const int blocks = dss::ceil_div((int)M, Cfg::ROWS);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case DSS_F16:
+      hipLaunchKernelGGL((dss::patch_embed_kres_kernel<dss::f16>), dim3(blocks), dim3(512), 0, s, img_u8, (const dss::f16*)Wp,
+                         (const dss::f16*)biasp, pos, x, (int)M, D, Np, H, W, Wpat);
+      break;
+#ifndef DSS_LIN_LAB_MIN
+    case DSS_BF16:
+      hipLaunchKernelGGL((dss::patch_embed_kres_kernel<dss::bf16>), dim3(blocks), dim3(512), 0, s, img_u8, (const dss::bf16*)Wp,
+                         (const dss::bf16*)biasp, pos, x, (int)M, D, Np, H, W, Wpat);
+      break;
+#endif
+    default: return dss::fail(DSS_ERR_BAD_ARG, "dss_patch_embed_p16: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
+  }
+  DSS_CHECK_LAUNCH("dss_patch_embed_p16");
+  return DSS_OK;
 }
 
 extern "C" int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,

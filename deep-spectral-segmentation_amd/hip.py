@@ -40,6 +40,7 @@ SYMBOLS = {
                                   c_int, c_int, c_void_p]),
     "dss_lnlinear_kfeatures_k384": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dss_patch_embed_p16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
     "dss_affinity_elems": (c_size_t, [c_int]),
@@ -252,6 +253,39 @@ def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu:
                                               m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
                                               _stream()), entry)
     return out
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def patch_embed16_prepare(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype):
+    """Fold ToTensor + Normalize into a 16 x 16 PatchEmbed: conv ``weight [D, 3, 16, 16]`` / ``[D, 768]`` in (c, py, px) order and
+    ``bias [D]`` -> ``(Wp [D, 768] in (py, px, c) order scaled by 1 / (255 std_c), biasp [D])`` in ``dtype`` for ``patch_embed16``
+    (sums in fp64: built once per model)."""
+    d = weight.shape[0]
+    w = weight.detach().double().reshape(d, 3, 16, 16)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
+    bp = bias.detach().double() - (w * (mean / std)).sum(dim=(1, 2, 3))
+    wp = (w / (255.0 * std)).permute(0, 2, 3, 1).reshape(d, 768)
+    return wp.to(dtype).contiguous(), bp.to(dtype).contiguous()
+
+
+def patch_embed16(img_u8: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, pos: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """u8 images ``[B, H, W, 3]`` -> rows ``1 .. Np`` of the fp32 residual stream ``x [B, Np + 1, D]``: transform, crop to whole
+    16 x 16 patches, patch embedding and ``+ pos [Np, D]`` in one kernel (``dss_patch_embed_p16``; ``wp, bp`` from
+    ``patch_embed16_prepare``).  Row 0 of every image (the CLS token) is left to the caller."""
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3 and img_u8.is_contiguous()
+    b, h, w, _ = img_u8.shape
+    n_p = (h // 16) * (w // 16)
+    d = wp.shape[0]
+    assert tuple(wp.shape) == (d, 768) and tuple(bp.shape) == (d,) and bp.dtype == wp.dtype
+    assert pos.dtype == torch.float32 and tuple(pos.shape) == (n_p, d) and pos.is_contiguous()
+    assert x.dtype == torch.float32 and tuple(x.shape) == (b, n_p + 1, d) and x.is_contiguous()
+    with _timed("patch_embed", m=b * n_p, n=d, k=768):
+        _check(load_library().dss_patch_embed_p16(_dev(img_u8, "img"), _dev(wp, "Wp"), _dev(bp, "biasp"), _dev(pos, "pos"), _dev(x, "x"),
+                                                  b, h, w, d, dtype_code(wp.dtype), _stream()), "dss_patch_embed_p16")
+    return x
 
 
 def lnlinear_prepare(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,

@@ -84,7 +84,7 @@ class DinoViT:
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
-                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True):
+                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -135,6 +135,10 @@ class DinoViT:
         self.pos_embed = sd["pos_embed"].detach().float().cpu()
         self.pe_w = lp(sd["patch_embed.proj.weight"].reshape(d, -1))  # [D, 3*P*P], (c, py, px) inner order
         self.pe_b = lp(sd["patch_embed.proj.bias"])
+        # fuse_ln builds at patch size 16: transform + patch embedding + position embedding as one kernel from the u8 image
+        self.pe16 = None
+        if self.patch_size == 16 and fuse_pe and fuse_ln and linear_kres and d % 64 == 0:
+            self.pe16 = hip.patch_embed16_prepare(sd["patch_embed.proj.weight"].to(self.device), sd["patch_embed.proj.bias"].to(self.device), dtype)
         self.blocks = []
         for i in range(self.depth):
             p = f"blocks.{i}."
@@ -189,13 +193,16 @@ class DinoViT:
         p, d, heads = self.patch_size, self.embed_dim, self.num_heads
         hp, wp = h // p, w // p
         t = hp * wp + 1
-        patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
-        with hip._timed("library_gemm", m=b * hp * wp, n=d, k=patches.shape[-1], what="patch_embed"):
-            tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
         cls_row, pos = self._pos(hp * p, wp * p)
         x = torch.empty((b, t, d), dtype=torch.float32, device=self.device)  # fp32 residual stream
         x[:, 0] = cls_row
-        torch.add(tok, pos, out=x[:, 1:])
+        if self.pe16 is not None:
+            hip.patch_embed16(img_u8.contiguous(), self.pe16[0], self.pe16[1], pos, x)
+        else:
+            patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
+            with hip._timed("library_gemm", m=b * hp * wp, n=d, k=patches.shape[-1], what="patch_embed"):
+                tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
+            torch.add(tok, pos, out=x[:, 1:])
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
         # K-resident Linear kernel: at D = 384 it beats the library GEMM on qkv, proj and fc1+GELU.  At D = 768 (one

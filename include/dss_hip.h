@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DSS_ABI_VERSION 5
+#define DSS_ABI_VERSION 6
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -122,6 +122,17 @@ int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps,
  * f16 operands only; 64 < T, M * T < 2^32.  Replaces dss_layernorm_fwd + a library GEMM + dss_kfeatures_finalize. */
 int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
                                 float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream);
+
+/* ---- a3 + a5 + a6 (first step): ToTensor + Normalize, the crop to whole patches, DINO's PatchEmbed Conv2d(3, D, 16, 16) and
+ * `x = cat(cls, tokens) + pos_embed` for the patch rows, in ONE kernel from the u8 image (extract/extract_utils.py:55-56,
+ * extract/extract.py:82-88).  img_u8 [B, H, W, 3]; Wp [D, 768] and biasp [D] in `dtype` are the caller's
+ * FOLDED parameters: Wp[n][(py, px, c)] = W[n][c][py][px] / (255 std_c), biasp[n] = b[n] - sum W[n][c][py][px] mean_c / std_c, so
+ * that the operand is the raw pixel value (0..255: exact in f16 and bf16); pos [Np, D] f32 = the (interpolated) position embedding
+ * of the patches; x [B, Np + 1, D] f32: rows 1..Np of every image are written (row 0, the CLS token, is the caller's).
+ * Patch size 16 only (K = 3 * 16 * 16 = 768: the K-resident kernel of linear384.hip gathers a patch as its operand row);
+ * D % 64 == 0, D <= 3072.  Replaces dss_preprocess_patchify + a GEMM + an elementwise pass. */
+int dss_patch_embed_p16(const uint8_t* img_u8, const void* Wp, const void* biasp, const float* pos, float* x, int B, int H, int W,
+                        int D, int dtype, void* stream);
 
 /* ---- a10: row L2 normalisation -------------------------------------------------------------
  * extract/extract.py:148  F.normalize(feats, p=2, dim=-1):  y = x / max(||x||_2, eps). */

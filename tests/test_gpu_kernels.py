@@ -313,6 +313,40 @@ def test_lnlinear_kfeatures_rejects_bad_arguments():
         hip.lnlinear_kfeatures(torch.zeros(1, 64, 384, device=DEV), None, wg, aux, 1e-6)
 
 
+@pytest.mark.parametrize("b,h,w,d", [(2, 480, 480, 384), (1, 224, 224, 384), (3, 37, 52, 384), (1, 16, 16, 384), (2, 130, 245, 768),
+                                     (5, 64, 48, 384), (1, 333, 500, 384)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_patch_embed16_matches_transform_conv_and_position_embedding(b, h, w, d, dtype):
+    """dss_patch_embed_p16 (u8 image -> fp32 residual-stream rows) against the fp64 composition it replaces: ToTensor + Normalize,
+    crop to whole patches, Conv2d(3, D, 16, 16), + position embedding; and against the three-pass path (patchify + GEMM + add).
+    Sizes that are not multiples of the patch (crop), of 8 (unaligned 8-byte gathers) and a single patch; row 0 of every image
+    and everything outside x untouched."""
+    g = torch.Generator().manual_seed(h * 7 + w + d)
+    img = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8)
+    wt = torch.randn(d, 3, 16, 16, generator=g) * 0.03
+    bias = torch.randn(d, generator=g) * 0.1
+    hp, wp_ = h // 16, w // 16
+    n_p = hp * wp_
+    pos = torch.randn(n_p, d, generator=g) * 0.5
+    wp, bp = hip.patch_embed16_prepare(wt.to(DEV), bias.to(DEV), dtype)
+    xbig = torch.full((b + 2, n_p + 1, d), 7.0, device=DEV)
+    hip.patch_embed16(img.to(DEV), wp, bp, pos.to(DEV), xbig[1:1 + b])
+    torch.cuda.synchronize()
+    assert bool((xbig[0] == 7).all()) and bool((xbig[1 + b:] == 7).all()) and bool((xbig[1:1 + b, 0] == 7).all())
+    mean = torch.tensor(hip.IMAGENET_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(hip.IMAGENET_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    t = (img[:, :hp * 16, :wp_ * 16].permute(0, 3, 1, 2).double() / 255.0 - mean) / std
+    ref = F.conv2d(t, wt.double(), bias.double(), stride=16).flatten(2).transpose(1, 2) + pos.double()
+    got = xbig[1:1 + b, 1:].cpu().double()
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= tol
+    # the three passes it replaces, same dtype: same quantity, their own roundings
+    patches = hip.preprocess_patchify(img.to(DEV), 16, dtype)
+    tok = F.linear(patches, wt.reshape(d, -1).to(DEV, dtype), bias.to(DEV, dtype)).float() + pos.to(DEV)
+    assert (tok.cpu().double() - ref).abs().max().item() <= 2 * tol
+    assert (got - tok.cpu().double()).abs().max().item() <= 2 * tol
+
+
 def test_kfeatures_finalize_writes_into_caller_slices():
     """`out=`: several ViT forwards fill ONE step's buffers (bench.py step_fed) - same values as the allocating form, nothing
     outside the slices touched."""
