@@ -28,6 +28,7 @@ KEYS = {  # bench.py kernel key -> substring of the rocprof kernel name (or a pr
     "linear_kres": lambda n: _kres_lnm(n) == 0,
     "lnlinear": lambda n: _kres_lnm(n) in (1, 2),
     "lnlinear_kfeatures": "kfeat_kres_kernel",
+    "patch_embed": "patch_embed_kres_kernel",
     "attention": "attn_fwd",
     "laplacian_eigs": "laplacian_eigs_kernel",
     "affinity": "gram_",
