@@ -260,18 +260,23 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 def patch_embed16_prepare(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype):
     """Fold ToTensor + Normalize into a 16 x 16 PatchEmbed: conv ``weight [D, 3, 16, 16]`` / ``[D, 768]`` in (c, py, px) order and
-    ``bias [D]`` -> ``(Wp [D, 768] in (py, px, c) order scaled by 1 / (255 std_c), biasp [D])`` in ``dtype`` for ``patch_embed16``
-    (sums in fp64: built once per model)."""
+    ``bias [D]`` -> ``(Wp [D, 768] in (py, px, c) order scaled by 1 / (255 std_c) in dtype, biasp [D] FP32)`` for
+    ``patch_embed16`` (sums in fp64: built once per model).  The folded bias is several times larger than the conv's own
+    (it carries ``sum W mean / std``): callers keep it in fp32 by adding it to the position-embedding rows they pass
+    (``patch_embed16(..., bp=None, pos=pos + biasp)``) instead of letting the kernel round it to ``dtype``."""
     d = weight.shape[0]
     w = weight.detach().double().reshape(d, 3, 16, 16)
     mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
     bp = bias.detach().double() - (w * (mean / std)).sum(dim=(1, 2, 3))
     wp = (w / (255.0 * std)).permute(0, 2, 3, 1).reshape(d, 768)
-    return wp.to(dtype).contiguous(), bp.to(dtype).contiguous()
+    return wp.to(dtype).contiguous(), bp.float().contiguous()
 
 
-def patch_embed16(img_u8: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, pos: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+_ZERO_BIAS: dict = {}
+
+
+def patch_embed16(img_u8: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tensor], pos: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """u8 images ``[B, H, W, 3]`` -> rows ``1 .. Np`` of the fp32 residual stream ``x [B, Np + 1, D]``: transform, crop to whole
     16 x 16 patches, patch embedding and ``+ pos [Np, D]`` in one kernel (``dss_patch_embed_p16``; ``wp, bp`` from
     ``patch_embed16_prepare``).  Row 0 of every image (the CLS token) is left to the caller."""
@@ -279,6 +284,13 @@ def patch_embed16(img_u8: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, pos:
     b, h, w, _ = img_u8.shape
     n_p = (h // 16) * (w // 16)
     d = wp.shape[0]
+    if bp is None:      # the bias travels inside `pos` (fp32): the kernel's own bias operand is zero
+        key = (d, wp.dtype, wp.device)
+        if key not in _ZERO_BIAS:
+            _ZERO_BIAS[key] = torch.zeros(d, dtype=wp.dtype, device=wp.device)
+        bp = _ZERO_BIAS[key]
+    else:
+        bp = bp.to(wp.dtype)
     assert tuple(wp.shape) == (d, 768) and tuple(bp.shape) == (d,) and bp.dtype == wp.dtype
     assert pos.dtype == torch.float32 and tuple(pos.shape) == (n_p, d) and pos.is_contiguous()
     assert x.dtype == torch.float32 and tuple(x.shape) == (b, n_p + 1, d) and x.is_contiguous()

@@ -169,7 +169,7 @@ class DinoViT:
         self.norm_b = f32(sd["norm.bias"]) if "norm.bias" in sd else None
         self.scale = 64 ** -0.5
         assert d // self.num_heads == 64, "DINO ViTs use 64-dim heads"
-        self._pos_cache: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._pos_cache: Dict[tuple, object] = {}   # (h, w) -> (cls row, pos rows); ("pe16", h, w) -> pos rows + folded bias
         if gemm_tuning not in ("table", "online", "off"):
             raise ValueError("gemm_tuning must be 'table' (shipped TunableOp table), 'online' (also tune new shapes) or 'off'")
         setup_gemm_tuning(tune_new_shapes=gemm_tuning == "online", use_table=gemm_tuning != "off")
@@ -197,7 +197,10 @@ class DinoViT:
         x = torch.empty((b, t, d), dtype=torch.float32, device=self.device)  # fp32 residual stream
         x[:, 0] = cls_row
         if self.pe16 is not None:
-            hip.patch_embed16(img_u8.contiguous(), self.pe16[0], self.pe16[1], pos, x)
+            key = ("pe16", hp * p, wp * p)
+            if key not in self._pos_cache:   # position embedding + the folded bias, both fp32: the kernel adds them in its epilogue
+                self._pos_cache[key] = (pos + self.pe16[1]).contiguous()
+            hip.patch_embed16(img_u8.contiguous(), self.pe16[0], None, self._pos_cache[key], x)
         else:
             patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
             with hip._timed("library_gemm", m=b * hp * wp, n=d, k=patches.shape[-1], what="patch_embed"):
