@@ -146,7 +146,8 @@ __device__ int dss_lin_stagger[2];
 // (through the transpose patch, as every other output) and rnorm = 1 / max(|k16 row|, eps); CLS rows are computed and dropped.
 // MODE 4 (patch embedding, dss_patch_embed_p16): DINO's PatchEmbed Conv2d(3, D, 16, 16) + `x = tokens + pos_embed[1:]` straight from
 // the u8 image: a lane's operand row is one 16 x 16 x 3 patch, gathered as 8-byte pieces of its 48-byte pixel rows (k order (py, px,
-// c); ToTensor / Normalize are folded into the weight and bias by the caller), the values 0..255 are exact in f16 / bf16; the
+// c); ToTensor / Normalize are folded into the weight and bias by the caller), the operand is pixel - 128 (-128..127: exact in f16 /
+// bf16, and centred so that the rounding of the folded weight multiplies a deviation, not the 0..255 level); the
 // epilogue adds the position embedding of the patch and writes fp32 rows b (Np + 1) + n + 1 of the residual stream - no patchify
 // pass, no f16 token tensor, no position-embedding pass.  k32 = x, Tn = Np, img / pos / H / W / Wp as named.
 struct KfOut { float* k32; float* rnorm; int Tn; float eps; const unsigned char* img; const float* pos; int H, W, Wp; };
@@ -204,7 +205,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       const u32x2v raw = *reinterpret_cast<const u32x2v*>(psrc + off);
       V8 fr;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fr[e] = from_f32<T>((float)((raw[e >> 2] >> (8 * (e & 3))) & 0xffu));
+      for (int e = 0; e < 8; ++e) fr[e] = from_f32<T>((float)((raw[e >> 2] >> (8 * (e & 3))) & 0xffu) - 128.0f);   // centred: see KfOut
       a[0][s] = fr;
     });
   } else if constexpr (LNM == 0) {

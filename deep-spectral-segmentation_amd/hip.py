@@ -260,7 +260,8 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 def patch_embed16_prepare(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype):
     """Fold ToTensor + Normalize into a 16 x 16 PatchEmbed: conv ``weight [D, 3, 16, 16]`` / ``[D, 768]`` in (c, py, px) order and
-    ``bias [D]`` -> ``(Wp [D, 768] in (py, px, c) order scaled by 1 / (255 std_c) in dtype, biasp [D] FP32)`` for
+    ``bias [D]`` -> ``(Wp [D, 768] in (py, px, c) order scaled by 1 / (255 std_c) in dtype, biasp [D] FP32 = b - sum W (mean_c -
+    128 / 255) / std_c: the kernel's operand is pixel - 128)`` for
     ``patch_embed16`` (sums in fp64: built once per model).  The folded bias is several times larger than the conv's own
     (it carries ``sum W mean / std``): callers keep it in fp32 by adding it to the position-embedding rows they pass
     (``patch_embed16(..., bp=None, pos=pos + biasp)``) instead of letting the kernel round it to ``dtype``."""
@@ -268,7 +269,7 @@ def patch_embed16_prepare(weight: torch.Tensor, bias: torch.Tensor, dtype: torch
     w = weight.detach().double().reshape(d, 3, 16, 16)
     mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=torch.float64, device=w.device).view(1, 3, 1, 1)
-    bp = bias.detach().double() - (w * (mean / std)).sum(dim=(1, 2, 3))
+    bp = bias.detach().double() - (w * ((mean - 128.0 / 255.0) / std)).sum(dim=(1, 2, 3))   # the kernel's operand is pixel - 128
     wp = (w / (255.0 * std)).permute(0, 2, 3, 1).reshape(d, 768)
     return wp.to(dtype).contiguous(), bp.float().contiguous()
 

@@ -126,8 +126,9 @@ int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, 
 /* ---- a3 + a5 + a6 (first step): ToTensor + Normalize, the crop to whole patches, DINO's PatchEmbed Conv2d(3, D, 16, 16) and
  * `x = cat(cls, tokens) + pos_embed` for the patch rows, in ONE kernel from the u8 image (extract/extract_utils.py:55-56,
  * extract/extract.py:82-88).  img_u8 [B, H, W, 3]; Wp [D, 768] and biasp [D] in `dtype` are the caller's
- * FOLDED parameters: Wp[n][(py, px, c)] = W[n][c][py][px] / (255 std_c), biasp[n] = b[n] - sum W[n][c][py][px] mean_c / std_c, so
- * that the operand is the raw pixel value (0..255: exact in f16 and bf16); pos [Np, D] f32 = the (interpolated) position embedding
+ * FOLDED parameters: Wp[n][(py, px, c)] = W[n][c][py][px] / (255 std_c), biasp[n] = b[n] - sum W[n][c][py][px] (mean_c - 128 / 255) /
+ * std_c, so that the operand is pixel - 128 (-128..127: exact in f16 and bf16, and centred, so that the rounding of Wp scales a
+ * deviation and not the 0..255 level); pos [Np, D] f32 = the (interpolated) position embedding
  * of the patches (a caller that wants the folded bias - several times the conv's own - unrounded adds it to these rows and
  * passes biasp = zeros: that is what the package does); x [B, Np + 1, D] f32: rows 1..Np of every image are written (row 0, the CLS token, is the caller's).
  * Patch size 16 only (K = 3 * 16 * 16 = 768: the K-resident kernel of linear384.hip gathers a patch as its operand row);
