@@ -284,3 +284,32 @@ def test_integration_md_binding_stub_matches_the_declared_abi():
         assert len([a for a in args.split(",") if a.strip()]) == len(hip.SYMBOLS[name][1]), name
     for name in re.findall(r"_lib\.(dss_[a-z0-9_]+)\(", block):
         assert name in hip.SYMBOLS, name
+
+
+def test_patch_embed16_prepare_folds_transform_and_centring_exactly():
+    """hip.patch_embed16_prepare (host side of dss_patch_embed_p16): with the kernel's operand = pixel - 128 in (py, px, c) order,
+    Wp . operand + biasp must BE Conv2d(Normalize(ToTensor(image))) - checked in fp64 with the unrounded folded weight - and the
+    rounded weight's error must scale with the centred operand, not with the 0..255 level."""
+    import torch
+    import torch.nn.functional as F
+    from dss_amd import hip
+
+    g = torch.Generator().manual_seed(5)
+    d = 64
+    w = torch.randn(d, 3, 16, 16, generator=g) * 0.03
+    b = torch.randn(d, generator=g) * 0.1
+    img = torch.randint(0, 256, (3, 32, 48, 3), generator=g, dtype=torch.uint8)
+    wp64, bp = hip.patch_embed16_prepare(w, b, torch.float64)
+    wp16, bp16 = hip.patch_embed16_prepare(w, b, torch.float16)
+    assert bp.dtype == torch.float32 and torch.equal(bp, bp16) and wp16.dtype == torch.float16 and tuple(wp16.shape) == (d, 768)
+    mean = torch.tensor(hip.IMAGENET_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(hip.IMAGENET_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    t = (img.permute(0, 3, 1, 2).double() / 255.0 - mean) / std
+    ref = F.conv2d(t, w.double(), b.double(), stride=16).flatten(2).transpose(1, 2)            # [B, Np, D]
+    # the kernel's operand rows: patch (py, px, c) order, centred
+    pat = img.double().reshape(3, 2, 16, 3, 16, 3).permute(0, 1, 3, 2, 4, 5).reshape(3, 6, 768) - 128.0
+    got = pat @ wp64.t() + bp.double()
+    assert (got - ref).abs().max().item() < 2e-6            # biasp is stored in fp32: that rounding only
+    got16 = pat @ wp16.double().t() + bp.double()
+    uncentred = (pat + 128.0) @ wp16.double().t() + (b.double() - (w.double() * (mean / std)).sum(dim=(1, 2, 3)))
+    assert (got16 - ref).abs().max().item() < (uncentred - ref).abs().max().item()
