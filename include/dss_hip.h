@@ -25,6 +25,8 @@
 extern "C" {
 #endif
 
+/* 6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
+ * only ever added: a caller built against version n runs against any library with dss_abi_version() >= n. */
 #define DSS_ABI_VERSION 6
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
