@@ -1,7 +1,8 @@
+// kres_r4_lab.h - lab snapshot of csrc/kres.h with the DSS_GELU_SCALAR branch (see linear384_r4_lab.hip).
 // kres.h - pieces of the K-resident Linear kernel (linear384.hip): LDS-DMA helper types and the
 // exact-erf GELU on packed fp32.
 #pragma once
-#include "common.h"
+#include "../../deep-spectral-segmentation_amd/csrc/common.h"
 
 namespace dss {
 
@@ -14,6 +15,37 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // below the f16 rounding of the output.  The chain of one value is 17 dependent VALU ops (the probe measures
 // latency-, not issue-bound execution), so NP pairs are advanced in lockstep: every step below is NP independent
 // v_pk_* instructions.
+#ifdef DSS_GELU_SCALAR   // lab (build with -fno-slp-vectorize): the same arithmetic on one-result instructions
+template <int NP>
+__device__ __forceinline__ void gelu_erf2xn(f32x2* x) {
+  float z[2 * NP], q[2 * NP];
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) z[j] = fabsf(x[j >> 1][j & 1]) * 0.70710678118654752f;
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(z[j], 0.0000430638f, 0.0002765672f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(q[j], z[j], 0.0001520143f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(q[j], z[j], 0.0092705272f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(q[j], z[j], 0.0422820123f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(q[j], z[j], 0.0705230784f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = fmaf(q[j], z[j], 1.0f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) q[j] = q[j] * q[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = __builtin_amdgcn_rcpf(q[j]);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) q[j] = (1.0f - q[j]) * (z[j] * 0.70710678118654752f);
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) x[j >> 1][j & 1] = fmaf(x[j >> 1][j & 1], 0.5f, q[j]);
+}
+#else
 template <int NP>
 __device__ __forceinline__ void gelu_erf2xn(f32x2* x) {
   f32x2 z[NP], q[NP];
@@ -51,5 +83,6 @@ __device__ __forceinline__ void gelu_erf2xn(f32x2* x) {
 #pragma unroll
   for (int j = 0; j < NP; ++j) x[j] = x[j] * 0.5f + q[j];
 }
+#endif
 
 }  // namespace dss

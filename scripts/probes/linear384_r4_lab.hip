@@ -1,3 +1,8 @@
+// linear384_r4_lab.hip - LAB SNAPSHOT of csrc/linear384.hip as of round 4, with every lab branch that file used to carry
+// (DSS_LIN_LAB_PIPE, DSS_LIN_LAB_STAGGER, DSS_LIN_LAB_RT1, DSS_LIN_LAB_MIN, DSS_LIN_ABL, DSS_LIN_PLAIN_PREFETCH,
+// DSS_LINEAR_NO_BARRIER, DSS_GELU_SCALAR).  Round 5 moved them here: the product file builds exactly one schedule.  Not part
+// of libdss_hip.so; scripts/probes/linear_{rt1,pipe}_lab.hip include it, scripts/build_lablib.sh links it against the product
+// objects in place of linear384.o (results of these builds: profiles/r03_linear_lab.txt, profiles/r04_linear_lab.txt).
 // linear384.hip - Linear layers of the DINO ViTs whose reduction dimension is the embedding width:
 // qkv (D -> 3D), attn.proj (D -> D), mlp.fc1 (D -> 4D, + exact GELU), for D = 384 (vits16 / vits8: the kernel was
 // designed on these shapes, hence the file name) and D = 768 (vitb16 / vitb8).
@@ -43,12 +48,11 @@
 //     dss_lnlinear_kfeatures_k384; see KfOut): read-only prologue, fp32 features from the accumulators + f16 copy + inverse
 //     row norms, CLS rows dropped.
 //   * K = 384 runs FOUR waves per workgroup and two workgroups per CU (see LinCfg); K = 768 eight waves, one workgroup.
-//   * this file builds exactly ONE schedule.  The lab variants of rounds 2-4 (ablations, plain prefetch, one tile per wave with
-//     three waves per SIMD, one wave per SIMD with the epilogue inside the next chunk's MFMAs, staggered workgroups, scalar GELU;
-//     results in profiles/r0N_linear_lab.txt, none shipped) live in scripts/probes/linear384_r4_lab.hip.  The only hook left is
-//     DSS_LIN_TIMELINE (instrumentation of THIS schedule, scripts/probes/linear_lab.hip); it compiles to nothing in the library.
-#include "common.h"
-#include "kres.h"
+//   * lab builds (results documented in profiles/r0N_linear_lab.txt, none shipped): DSS_LIN_TIMELINE, DSS_LIN_ABL,
+//     DSS_LIN_PLAIN_PREFETCH, DSS_LIN_LAB_RT1 (one tile per wave, three waves per SIMD), DSS_LIN_LAB_PIPE (one wave per SIMD,
+//     the epilogue inside the next chunk's MFMAs), DSS_LIN_LAB_STAGGER, DSS_GELU_SCALAR (kres.h).
+#include "../../deep-spectral-segmentation_amd/csrc/common.h"
+#include "kres_r4_lab.h"
 #include <utility>
 
 // scripts/probes/linear_lab.hip includes this file with DSS_LIN_TIMELINE defined: wave 0 of every workgroup adds the shader
@@ -114,12 +118,12 @@ template <int NUNIT, int NXS, bool RES, bool ST = RES> struct LnSched {   // ST:
 // under the other's MFMAs).  Measured EQUAL to the eight-wave workgroup of rounds 1-2 (qkv 258 vs 255-272 us, fc1+GELU
 // 425-451 vs 435-453; scripts/debug/linear_ab.py) and kept for the smaller LDS footprint; K = 768 keeps eight waves (its
 // 96 KB of W buffers admit one workgroup per CU either way).  What the lab's ablations say about this kernel (same script,
-// ablation builds of the lab snapshot): no epilogue 209 us, no stores 222 us, every A fragment the SAME 16 bytes 130 us - but that last
+// DSS_LIN_ABL builds): no epilogue 209 us, no stores 222 us, every A fragment the SAME 16 bytes 130 us - but that last
 // build also feeds the MFMAs constant operands, and on this part a dense MFMA stream runs 2.2-2.5 PFLOP/s on constant
 // operands against 1.68 on random ones (profiles/r01_mfma_ceiling_probe.txt): the number is a clock effect as much as an
 // A-stream effect, and neither full-line LDS-DMA loads of A nor two workgroups per CU moved the real-data time.
 template <int KS, int RT, int NW> struct LinCfg {
-  static_assert(KS * RT == 48 && KS % NW == 0, "the A operand of a wave is 48 fragments");
+  static_assert((KS * RT == 48 || KS * RT == 24) && KS % NW == 0, "the A operand of a wave is 48 (or, lab, 24) fragments");
   static constexpr int WAVES = NW, THREADS = 64 * NW;
   static constexpr int K = 16 * KS;
   static constexpr int ROWS_WAVE = 32 * RT;
@@ -132,7 +136,15 @@ template <int KS, int RT, int NW> struct LinCfg {
 
 // LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
 // res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
-// MODE 0: the Linear layer (output C, row-major or DSS_PLANAR64).
+#ifdef DSS_LIN_LAB_STAGGER
+// Lab (scripts/debug/lin_stagger_ab.py): the workgroups of the FIRST round that are expected to be a CU's second tenant wait
+// before their prologue, so that the two workgroups of a CU are half a period apart from then on (one in its HBM-bound
+// prologue while the other is in its chunk loop) instead of in lockstep.  [0] = which workgroups (1: ids 256..511, 2: odd ids,
+// 3: ids with bit 3 set), [1] = the wait in wall-clock ticks (10 ns).
+__device__ int dss_lin_stagger[2];
+#endif
+// PIPE (lab, DSS_LIN_LAB_PIPE): ONE wave per SIMD owns all 512 registers and overlaps the epilogue of chunk c - 1 with the MFMAs
+// of chunk c (see the chunk loop).
 // MODE 2 (K-feature hand-over, dss_lnlinear_kfeatures_k384): the output of the LAST block's K projection leaves as what the
 // caller and the affinity build need - token rows b * Tn + t, t >= 1, go to row b * (Tn - 1) + t - 1 of k32 (fp32, straight
 // from the accumulators: 16-byte pieces, a 32-column chunk of a row is one 128-byte line written by one wave), of C = k16
@@ -145,7 +157,7 @@ template <int KS, int RT, int NW> struct LinCfg {
 // pass, no f16 token tensor, no position-embedding pass.  k32 = x, Tn = Np, img / pos / H / W / Wp as named.
 struct KfOut { float* k32; float* rnorm; int Tn; float eps; const unsigned char* img; const float* pos; int H, W, Wp; };
 
-template <class T, bool GELU, int KS, int RT, int NW, int LNM, int MODE>
+template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE>
 __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float* __restrict__ X,
                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                  const T* __restrict__ W,
@@ -165,6 +177,16 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   const bool block_full = mrem >= LBM;
 
   DSS_TL_DECL
+#ifdef DSS_LIN_LAB_STAGGER
+  {
+    const int mode = dss_lin_stagger[0], b = blockIdx.x;
+    const bool late = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : mode == 3 ? (b >> 3) & 1 : 0);
+    if (late) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)dss_lin_stagger[1]) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
   // ---- this lane's RT token rows as MFMA B-operand fragments: k = 16 s + 8 hh + e ----------------------------
   // Through the wave's own LDS patch, 64 columns at a time: LDS-DMA pieces of 8 rows x 128 B (FULL lines of A, 8 lanes per
   // row; 16-byte chunk c of row r lands at position c ^ ((r >> 1) & 7): the swizzle is applied to the source address) and
@@ -173,7 +195,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // full lines do; measured equal in time (see LinCfg), kept for the 4x fewer L2 requests.
   V8 a[RT][LKS];
   float am[RT];                                            // LNM != 0: A side of the correction k-step (mean | sigma), per row tile
-  if constexpr (MODE == 4) {
+  if constexpr (PIPE == 4) {
     static_assert(RT == 1 && LK == 768, "one 16 x 16 x 3 patch per operand row");
     typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     const unsigned gp = (unsigned)min((int)blockIdx.x * LBM + rloc + li, M - 1);   // this lane's patch (M = B Np of them)
@@ -204,7 +226,11 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     for (int q = 0; q < NPIECE; ++q) {
       const int rowp = 8 * q + (lane >> 3);
       const unsigned ch = (unsigned)((lane & 7) ^ ((rowp >> 1) & 7));
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 1)   // lab ablation: no A stream (every piece re-reads the block's first row)
+      rowoff[q] = 16u * ch;
+#else
       rowoff[q] = (unsigned)min(rloc + rowp, mrem - 1) * (unsigned)(LK * 2) + 16u * ch;
+#endif
     }
     // Two landing buffers - the wave's patch and its share of the (still idle) W double buffer - so that round rd + 1 is in
     // flight while round rd's fragments are read: a round used to cost a full DMA round trip (issue, vmcnt(0), read), six
@@ -218,7 +244,11 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
 #pragma unroll
       for (int q = 0; q < NPIECE; ++q) {
         unsigned keep;
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 1)
+        const unsigned off = rowoff[q];
+#else
         const unsigned off = rowoff[q] + 128u * rd;
+#endif
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(pdst2[rd & 1] + 1024u * q), "v"(off), "s"(asrc) : "memory");
@@ -250,7 +280,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     constexpr int NSLOT = (WS_SHARE + Cfg::PATCH_BYTES) / 4096;
     constexpr int NXS = RES ? NSLOT - 2 : NSLOT;             // x slots (K = 384: 3 / 5; K = 768: 2 / 4); 2 residual slots
     static_assert(WS_SHARE % 4096 == 0 && Cfg::PATCH_BYTES % 4096 == 0 && NXS >= 2 && NCB % 2 == 0 && NUNIT <= 48, "LN prologue layout");
-    constexpr bool XST = RES && MODE != 2;                  // the hand-over kernel is the stream's LAST reader: x + res is used, not stored
+    constexpr bool XST = RES && PIPE != 2;                  // the hand-over kernel is the stream's LAST reader: x + res is used, not stored
     typedef LnSched<NUNIT, NXS, RES, XST> Sched;
     unsigned char* const ws_share = &Ws[0][0] + wave * WS_SHARE;
     unsigned char* const patch = &Stg[wave][0];
@@ -399,7 +429,9 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // chunks, whose arrival is awaited explicitly (wait_dma) by the issuing waves.
   auto phase_barrier = [&]() {
     asm volatile("" ::: "memory");
+#ifndef DSS_LINEAR_NO_BARRIER   // lab ablation (scripts/gpu_r3.sh linear_nobar): waves drift freely, results wrong
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   };
   // vmcnt retires in issue order (gfx9: loads, LDS-DMA and stores share it): with the 8 tile stores of an odd chunk
@@ -407,7 +439,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // stores - their HBM acknowledgements (~2 us under load, longer than a phase) then overlap the next phases.
   // Ragged workgroups predicate their stores (unknown count): they wait for everything.
   auto wait_dma = [&](int c_stored) {
-    if (MODE != 2 && MODE != 4 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
+    if (PIPE != 2 && PIPE != 4 && block_full && (c_stored & 1)) {          // (the hand-over mode predicates its stores per row: unknown counts)
       if (Cfg::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -449,7 +481,13 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     const unsigned wbase = (unsigned)(size_t)(lds_ptr_t)(&Ws[c & 1][0]) + 16u * (unsigned)lane;
     constexpr int PF = 2;
     V8 f[PF + 1];
+#ifndef DSS_LIN_PLAIN_PREFETCH   // lab ablation (scripts/build_lablib.sh): the plain C++ loads hipcc regroups
     static_for<PF>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read_b128_at<1024 * i>(f[i], wbase); });
+#else
+    const unsigned char* wb = &Ws[c & 1][16 * lane];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
+#endif
     const float bcol = to_f32<T>(bias_next);
     float wcorr = 0.f;
     if constexpr (LNM == 0) {
@@ -470,8 +508,12 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     __builtin_amdgcn_s_setprio(1);
     static_for<LKS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
+#ifndef DSS_LIN_PLAIN_PREFETCH
       if constexpr (s + PF < LKS) lds_read_b128_at<1024 * (s + PF)>(f[(s + PF) % (PF + 1)], wbase);
       lds_wait_for<(s + PF < LKS ? PF : LKS - 1 - s)>(f[s % (PF + 1)]);
+#else
+      if constexpr (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
+#endif
       if (RT == 2) {
         acc0 = mfma32x32x16(f[s % (PF + 1)], a[0][s], acc0);      // D[col][row] += W[col][k] * A[row][k]
         acc1 = mfma32x32x16(f[s % (PF + 1)], a[RT - 1][s], acc1);
@@ -499,11 +541,11 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- K-feature hand-over (MODE == 2, see KfOut): this lane's two accumulator rows -> output rows, their sums of squares
+  // ---- K-feature hand-over (PIPE == 2, see KfOut): this lane's two accumulator rows -> output rows, their sums of squares
   float kss[RT];
   unsigned kmagic = 0;                                     // gr / Tn = umulhi(gr, kmagic) for gr * Tn < 2^32 (host-checked)
-  if constexpr (MODE == 4) kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
-  if constexpr (MODE == 2) {
+  if constexpr (PIPE == 4) kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
+  if constexpr (PIPE == 2) {
     kmagic = __builtin_amdgcn_readfirstlane(0xFFFFFFFFu / (unsigned)kf.Tn + 1u);
 #pragma unroll
     for (int t = 0; t < RT; ++t) kss[t] = 0.f;
@@ -558,7 +600,11 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
         }
       }
     }
-    if constexpr (MODE == 4) {
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 4)   // lab ablation: no epilogue at all (accumulators kept alive)
+    asm volatile("" :: "v"(acc0), "v"(acc1));
+    return;
+#endif
+    if constexpr (PIPE == 4) {
       // tokens + position embedding -> fp32 rows of the residual stream, straight from the accumulators (no patch, no f16 output)
       typedef float f32x4v __attribute__((ext_vector_type(4)));
       const unsigned gp = blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + eli;
@@ -566,11 +612,6 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       const unsigned coloff = (unsigned)(c * LBN * 4) + 16u * ehh;
       const unsigned char* posr = reinterpret_cast<const unsigned char*>(kf.pos) + (gp - pb * (unsigned)kf.Tn) * (unsigned)(N * 4) + coloff;
       unsigned char* xr = reinterpret_cast<unsigned char*>(kf.k32) + (gp + pb + 1u) * (unsigned)(N * 4) + coloff;
-      // the two k-step chains are joined FIRST (and pinned there): the 16 registers of the odd chain are then free for the
-      // position rows - with the loads ahead of the sums hipcc kept all 48 values live and spilled 1 (f16) / 7 (bf16) VGPRs
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
-      asm volatile("" : "+v"(acc0));
       if ((int)gp < M) {
         f32x4v pe[4];
 #pragma unroll
@@ -579,13 +620,13 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
         for (int g = 0; g < 4; ++g) {
           f32x4v v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc0[4 * g + i] + pe[g][i];
+          for (int i = 0; i < 4; ++i) v[i] = acc0[4 * g + i] + acc1[4 * g + i] + pe[g][i];
           *reinterpret_cast<f32x4v*>(xr + 32 * g) = v;
         }
       }
       return;
     }
-    if constexpr (MODE == 2) {
+    if constexpr (PIPE == 2) {
       // (uniform base in SGPRs + 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic per lane)
       typedef float f32x4v __attribute__((ext_vector_type(4)));
       const unsigned half2 = 64u * (c & 1);
@@ -652,6 +693,9 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     if (!(c & 1)) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS write -> read (other lanes' data)
     unsigned char* cw = cblk + (size_t)(c >> 1) * gstride;
+#if defined(DSS_LIN_ABL) && (DSS_LIN_ABL & 2)   // lab ablation: no global stores
+    return;
+#endif
     if (block_full) {
 #pragma unroll
       for (int i = 0; i < Cfg::NSTORE; ++i)
@@ -670,6 +714,167 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   //      last read in chunk c - 1, behind the barrier that ended it) and awaited (wait_dma) before the barrier that ends
   //      chunk c.
   const int nchunks = N / LBN;
+#ifdef DSS_LIN_LAB_PIPE
+  // Lab (scripts/probes/linear_pipe_lab.hip): TWO accumulator sets - the epilogue of chunk c - 1 (GELU, pack, patch, stores)
+  // is in the same basic block as the MFMAs of chunk c and a sched_group_barrier sequence asks hipcc to interleave them
+  // (RT MFMAs, 1 LDS read, DSS_LIN_LAB_PIPE VALU, ...).  NW = 4: with RT = 1 two workgroups share a CU (2 waves / SIMD, 256
+  // registers each); with RT = 2 ONE wave per SIMD owns all 512 registers.  Full blocks only.
+  if constexpr (PIPE == 1 && LNM == 0) {
+    f32x16 accA[RT], accB[RT];
+    constexpr int PF = DSS_LIN_LAB_PIPE_PF;
+    // the epilogue of one g (4 accumulator registers of every tile = NP float2) as ten short stages, one behind each MFMA
+    constexpr int NP = 2 * RT, NSTG = 10, MPG = (LKS * RT) / 4;   // MFMAs per g
+    static_assert(MPG >= NSTG, "one stage per MFMA");
+    f32x2 gx[NP], gz[NP], gq[NP];
+    auto epi_stage = [&](int c, const f32x16 (&acc)[RT], int g, auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st == 0) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          gx[2 * t] = f32x2{acc[t][4 * g], acc[t][4 * g + 1]};
+          gx[2 * t + 1] = f32x2{acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        }
+        if (GELU) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) { gz[j][0] = fabsf(gx[j][0]); gz[j][1] = fabsf(gx[j][1]); }
+        }
+      }
+      if constexpr (GELU) {
+        if constexpr (st == 1) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gz[j] = gz[j] * 0.70710678118654752f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gz[j] * 0.0000430638f + 0.0002765672f;
+        } else if constexpr (st == 2) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0001520143f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0092705272f;
+        } else if constexpr (st == 3) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0422820123f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 0.0705230784f;
+        } else if constexpr (st == 4) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gz[j] + 1.0f;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+        } else if constexpr (st == 5) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+        } else if constexpr (st == 6) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = gq[j] * gq[j];
+#pragma unroll
+          for (int j = 0; j < NP / 2; ++j) { gq[j][0] = __builtin_amdgcn_rcpf(gq[j][0]); gq[j][1] = __builtin_amdgcn_rcpf(gq[j][1]); }
+        } else if constexpr (st == 7) {
+#pragma unroll
+          for (int j = NP / 2; j < NP; ++j) { gq[j][0] = __builtin_amdgcn_rcpf(gq[j][0]); gq[j][1] = __builtin_amdgcn_rcpf(gq[j][1]); }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gz[j] = gz[j] * 0.70710678118654752f;
+        } else if constexpr (st == 8) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gq[j] = (1.0f - gq[j]) * gz[j];
+        }
+      }
+      if constexpr (st == 9) {
+        if (GELU) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) gx[j] = gx[j] * 0.5f + gq[j];
+        }
+        unsigned char* stg_w = stg + li * 128 + 8 * hh;
+        const unsigned stg_x = 16u * ((li >> 1) & 7);
+        const unsigned half = 64u * (c & 1);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          V4 o0;
+          o0[0] = from_f32<T>(gx[2 * t][0]); o0[1] = from_f32<T>(gx[2 * t][1]); o0[2] = from_f32<T>(gx[2 * t + 1][0]); o0[3] = from_f32<T>(gx[2 * t + 1][1]);
+          *reinterpret_cast<V4*>(stg_w + ((half + 16 * g) ^ stg_x) + 4096 * t) = o0;
+        }
+      }
+    };
+    auto store_group = [&](int c) {       // c odd: the 64-column group c >> 1 is complete in the patch
+      const int rq = lane >> 3, pq = lane & 7;
+      const unsigned stg_ro = (unsigned)(rq * 128 + 16 * (pq ^ (rq >> 1)));
+      const unsigned coff = (unsigned)((rloc + rq) * (unsigned)ldc + 16 * pq);
+      unsigned char* cw = cblk + (size_t)(c >> 1) * gstride;
+#pragma unroll
+      for (int i = 0; i < Cfg::NSTORE; ++i)
+        __builtin_nontemporal_store(*reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i),
+                                    reinterpret_cast<V8*>(cw + (size_t)(8 * i) * ldc + coff));
+    };
+    // chunk c into `cur` while the epilogue of chunk c - 1 (in `prev`) runs in slices between its MFMAs: every SPU fragment
+    // steps one unit, hipcc told (sched_group_barrier) to alternate 1 MFMA / DSS_LIN_LAB_PIPE VALU inside the slice and
+    // (sched_barrier) to move nothing across its end
+    auto chunk = [&](int c, f32x16 (&cur)[RT], const f32x16 (&prev)[RT], bool with_prev, bool more) {
+      if (more) stage(c + 1);
+#if DSS_LIN_LAB_PIPE_RT == 2 && !defined(DSS_LIN_LAB_PIPE_NO_AGPR)
+      // the operand fragments live in the accumulation registers (the MFMA reads them there): the 256 architectural ones
+      // are for the two accumulator sets and the epilogue
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < LKS; ++s) asm volatile("" : "+a"(a[t][s]));
+#endif
+      const unsigned char* wb = &Ws[c & 1][16 * lane];
+      V8 f[PF + 1];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) f[i] = *reinterpret_cast<const V8*>(wb + 1024 * i);
+      const float bcol = to_f32<T>(bias_next);
+      bias_next = bias[min((c + 1) * LBN, N - LBN) + li];
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[t][r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<LKS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + PF < LKS) f[(s + PF) % (PF + 1)] = *reinterpret_cast<const V8*>(wb + 1024 * (s + PF));
+        static_for<RT>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int m = s * RT + t;                       // this chunk's m-th MFMA: stage m % MPG of g = m / MPG behind it
+          cur[t] = mfma32x32x16(f[s % (PF + 1)], a[t][s], cur[t]);
+          if constexpr (m % MPG < NSTG)
+            if (with_prev) epi_stage(c - 1, prev, m / MPG, std::integral_constant<int, m % MPG>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      V8 fb, a_one;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fb[e] = from_f32<T>((e == 0 && hh == 0) ? bcol : 0.0f);
+        a_one[e] = from_f32<T>((e == 0 && hh == 0) ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) cur[t] = mfma32x32x16(fb, a_one, cur[t]);
+    };
+    stage(0);
+    wait_vm();
+    __syncthreads();
+    chunk(0, accA, accB, false, true);
+    wait_vm();
+    phase_barrier();
+    int c = 1;
+    for (; c + 1 < nchunks; c += 2) {
+      chunk(c, accB, accA, true, true);          // odd chunk beside the epilogue of the even one: half a 64-column group, no stores
+      wait_vm();
+      phase_barrier();
+      chunk(c + 1, accA, accB, true, true);      // even chunk beside the epilogue of the odd one, then that group's stores
+      store_group(c);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::NSTORE) : "memory");
+      phase_barrier();
+    }
+    chunk(c, accB, accA, true, false);
+    static_for<4>([&](auto gc) {
+      static_for<NSTG>([&](auto stc) { epi_stage(c, accB, decltype(gc)::value, stc); });
+    });
+    store_group(c);
+    return;
+  }
+#endif
   stage(0);
   wait_vm();
   __syncthreads();
@@ -683,17 +888,17 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     phase_barrier();
     DSS_TL_MARK(3)
   }
-  if constexpr (MODE == 2) kf_finish();
+  if constexpr (PIPE == 2) kf_finish();
   DSS_TL_FLUSH
 }
 
-template <class T, bool GELU, int KS, int RT, int NW, int LNM, int MODE = 0>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
+template <class T, bool GELU, int KS, int RT, int NW, int LNM, int PIPE = 0>
+__global__ __launch_bounds__(64 * NW, (PIPE == 1 && RT == 2) || NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
                                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                                  const T* __restrict__ W,
                                                                  const T* __restrict__ bias, const float* __restrict__ aux,
                                                                  T* __restrict__ C, int M, int N, int planar) {
-  linear_kres_body<T, GELU, KS, RT, NW, LNM, MODE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, 0, 0});
+  linear_kres_body<T, GELU, KS, RT, NW, LNM, PIPE>(A, X, R, r_ld, r_plane, eps, W, bias, aux, C, M, N, planar, KfOut{nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, 0, 0});
 }
 
 // The K = 768 kernel as the patch embedding (mode 4): M = B Np patches, N = D.
@@ -736,15 +941,15 @@ __global__ __launch_bounds__(64) void lnlinear_prepare_kernel(const float* __res
   }
 }
 
-template <class T, int KS, int RT, int NW, int LNM, int MODE = 0>
+template <class T, int KS, int RT, int NW, int LNM, int PIPE = 0>
 static void launch_linear_kres(const void* A, float* X, const void* R, long r_ld, long r_plane, float eps, const void* W,
                                const void* bias, const float* aux, void* C, int M, int N, int gelu, int planar, hipStream_t s) {
   const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
   if (gelu)
-    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM, PIPE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
   else
-    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM, PIPE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
 }
 
@@ -773,7 +978,9 @@ static int linear_kres(const char* name, const void* A, float* X, const void* re
   } while (0)
   switch (dtype) {
     case DSS_F16: DSS_LAUNCH_KRES(f16); break;
+#ifndef DSS_LIN_LAB_MIN   // lab builds (quick compiles): f16 only
     case DSS_BF16: DSS_LAUNCH_KRES(bf16); break;
+#endif
     default: return fail(DSS_ERR_BAD_ARG, "%s: dtype must be DSS_F16 or DSS_BF16 (got %d)", name, dtype);
   }
 #undef DSS_LAUNCH_KRES
@@ -789,12 +996,14 @@ extern "C" int dss_linear_k384(const void* A, const void* W, const void* bias, v
   return dss::linear_kres<24, 2, 4>("dss_linear_k384", A, nullptr, nullptr, 0, 0.f, W, bias, nullptr, C, M, N, gelu, out_layout, dtype, stream);
 }
 
+#ifndef DSS_LIN_LAB_MIN
 extern "C" int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
                                int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(A, "dss_linear_k768: null pointer");
   return dss::linear_kres<48, 1, 8>("dss_linear_k768", A, nullptr, nullptr, 0, 0.f, W, bias, nullptr, C, M, N, gelu, out_layout, dtype, stream);
 }
 
+#endif
 
 extern "C" int dss_lnlinear_prepare(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg, float* aux,
                                     int N, int K, int dtype, void* stream) {
@@ -837,10 +1046,12 @@ extern "C" int dss_patch_embed_p16(const uint8_t* img_u8, const void* Wp, const 
       hipLaunchKernelGGL((dss::patch_embed_kres_kernel<dss::f16>), dim3(blocks), dim3(512), 0, s, img_u8, (const dss::f16*)Wp,
                          (const dss::f16*)biasp, pos, x, (int)M, D, Np, H, W, Wpat);
       break;
+#ifndef DSS_LIN_LAB_MIN
     case DSS_BF16:
       hipLaunchKernelGGL((dss::patch_embed_kres_kernel<dss::bf16>), dim3(blocks), dim3(512), 0, s, img_u8, (const dss::bf16*)Wp,
                          (const dss::bf16*)biasp, pos, x, (int)M, D, Np, H, W, Wpat);
       break;
+#endif
     default: return dss::fail(DSS_ERR_BAD_ARG, "dss_patch_embed_p16: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
   }
   DSS_CHECK_LAUNCH("dss_patch_embed_p16");
@@ -870,11 +1081,35 @@ extern "C" int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int r
   return DSS_OK;
 }
 
+#ifndef DSS_LIN_LAB_MIN
 extern "C" int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
                                  void* C, int M, int N, int gelu, int out_layout, int dtype, void* stream) {
   DSS_REQUIRE(x, "dss_lnlinear_k768: null pointer");
   return dss::linear_kres<48, 1, 8>("dss_lnlinear_k768", nullptr, x, residual, res_layout, eps, Wg, nullptr, aux, C, M, N, gelu, out_layout, dtype, stream);
 }
+#endif
 
+#ifdef DSS_LIN_LAB_RT1
+// Lab (scripts/probes): K = 384 with ONE 32-row tile per wave - 96 operand registers, so that THREE waves share a SIMD (two
+// workgroups of six waves per CU, 170 registers each) where the product runs two.  Plain Linear only.
+extern "C" int dss_linear_k384_rt1(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu,
+                                   int out_layout, void* stream) {
+  dss::launch_linear_kres<dss::f16, 24, 1, 6, 0>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu,
+                                                 out_layout == DSS_PLANAR64, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#endif
 
+#ifdef DSS_LIN_LAB_PIPE
+extern "C" int dss_linear_k384_pipe(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, void* stream) {
+  dss::launch_linear_kres<dss::f16, 24, DSS_LIN_LAB_PIPE_RT, 4, 0, 1>(A, nullptr, nullptr, 0, 0, 0.f, W, bias, nullptr, C, M, N, gelu, 0, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#endif
 
+#ifdef DSS_LIN_LAB_STAGGER
+extern "C" int dss_linear_set_stagger(int mode, int ticks) {
+  const int v[2] = {mode, ticks};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dss::dss_lin_stagger), v, sizeof(v)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -6,7 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDSS_LIN_LAB_PIPE=230 -DDSS_LIN_LAB_PIPE_RT=2 -DDSS_LIN_LAB_PIPE_PF=3
 //        scripts/probes/linear_pipe_lab.hip deep-spectral-segmentation_amd/csrc/lib.hip -o scripts/probes/linear_pipe_lab_r2p3n0
 //        (DSS_LIN_LAB_PIPE's value is only printed; _RT = row tiles per wave, _PF = W fragments read ahead)
-#include "../../deep-spectral-segmentation_amd/csrc/linear384.hip"
+#include "linear384_r4_lab.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>

@@ -2,7 +2,7 @@
 // wave (96 operand registers, <= 170 per wave, two workgroups of six waves per CU) against the product (two 32-row tiles per
 // wave, 256 registers, two waves per SIMD), same inputs, outputs compared.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDSS_LIN_LAB_RT1 scripts/probes/linear_rt1_lab.hip deep-spectral-segmentation_amd/csrc/lib.hip -o scripts/probes/linear_rt1_lab
-#include "../../deep-spectral-segmentation_amd/csrc/linear384.hip"
+#include "linear384_r4_lab.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>

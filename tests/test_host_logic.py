@@ -313,3 +313,28 @@ def test_patch_embed16_prepare_folds_transform_and_centring_exactly():
     got16 = pat @ wp16.double().t() + bp.double()
     uncentred = (pat + 128.0) @ wp16.double().t() + (b.double() - (w.double() * (mean / std)).sum(dim=(1, 2, 3)))
     assert (got16 - ref).abs().max().item() < (uncentred - ref).abs().max().item()
+
+
+def test_hot_kernels_have_no_register_spills_and_no_scratch():
+    """Code-object notes of the shipped library (scripts/code_object_notes.py): no kernel spills a VGPR or uses scratch memory -
+    a reload inside an MFMA / DMA loop shares vmcnt with the loads it sits between and drains them.
+    The product kernel file builds exactly one schedule: no lab branch is left in it."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("code_object_notes", REPO / "scripts" / "code_object_notes.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    notes = mod.kernel_notes(hip.LIB_PATH)
+    hot = ("linear_kres_kernel", "kfeat_kres_kernel", "patch_embed_kres_kernel", "attn_fwd_kernel", "laplacian_eigs_kernel",
+           "gram_f16_dma_kernel", "layernorm_kernel", "preprocess_patchify8", "kfeatures_finalize_kernel")
+    seen = {h: 0 for h in hot}
+    for name, r in notes.items():
+        for h in hot:
+            if h in name:
+                seen[h] += 1
+                assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+    assert all(seen.values()), seen
+    assert len(notes) > 50
+    src = (REPO / "deep-spectral-segmentation_amd" / "csrc" / "linear384.hip").read_text()
+    for lab in ("DSS_LIN_LAB", "DSS_LIN_ABL", "DSS_LINEAR_NO_BARRIER", "DSS_LIN_PLAIN_PREFETCH"):
+        assert lab not in src, lab
