@@ -1,6 +1,6 @@
 """Lab: do the two workgroups of a CU run the fused norm -> Linear kernel faster when they are HALF A PERIOD APART (one in its
 HBM-bound LayerNorm prologue while the other is in its MFMA chunk loop) than in lockstep?  Needs the lab library
-(scripts/build_lablib.sh stagger linear384.hip -DDSS_LIN_LAB_STAGGER; DSS_HIP_LIBRARY=scripts/lablib/libdss_hip_stagger.so):
+(scripts/build_lablib.sh stagger linear384_r4_lab.hip -DDSS_LIN_LAB_STAGGER; DSS_HIP_LIBRARY=scripts/lablib/libdss_hip_stagger.so):
 the first-round workgroups picked by `mode` wait `us` microseconds before their prologue."""
 import os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
