@@ -35,8 +35,10 @@
 //     (4 KB per unit, a ring of slots in the - still idle - W double buffer), the residual tile (32 rows x 64 columns of
 //     f16: two units) in the wave's transpose patch; the lane reads its fragment-shaped share, adds, accumulates
 //     pivot-shifted first and second moments of ITS two rows (a lane owns whole half rows: no butterfly, one lane^32
-//     exchange at the end), packs the raw sum into the resident A fragments, writes the f32 sums back into the slot and
-//     stores them as full lines.  The fragments STAY raw (f16(x): one rounding): (x - mean) rstd never exists - the mean and
+//     exchange at the end), packs the sum MINUS THE ROW'S PIVOT (round 5: a robust typical value of the row, so that the operand's
+//     rounding error scales with the row's spread and not with |x| - rows whose mean is far from zero) into the resident A
+//     fragments, writes the f32 sums back into the slot and stores them as full lines.  The fragments stay un-normalised
+//     (f16(x - pivot): one rounding): (x - mean) rstd never exists - the (mean - pivot) and
 //     sigma corrections are one fp32 MFMA k-step per chunk against the caller's table aux[col] = (-sum_k Wg, b') and the
 //     epilogue multiplies by rstd (gamma and beta are folded into W and the table by dss_lnlinear_prepare).
 //   * round 4: the hooked block's K projection is the same body in a hand-over mode (kfeat_kres_kernel,
@@ -318,7 +320,18 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
           for (int e = 0; e < 4; ++e) { v0[sl][e] += to_f32<T>(pv[e]); v1[sl][e] += to_f32<T>(pv[4 + e]); }
         }
       }
-      if (cb == 0) piv[t] = v0[0][0];
+      if constexpr (cb == 0) {
+        // the ROW's pivot (round 5; both lanes of a row use the hh = 0 lane's): the median of the medians of three column triples
+        // (columns 0-2, 4-6, 16-18: Tukey's ninther) - a typical value of the row unless FOUR of those nine columns are outlier
+        // channels (a pivot taken from a massive-activation channel would put every other column 2^-11 |outlier| from its value;
+        // trained ViTs have two or three such channels), within ~0.4 sigma of the row's centre otherwise
+        const float g0 = __builtin_amdgcn_fmed3f(v0[0][0], v0[0][1], v0[0][2]), g1 = __builtin_amdgcn_fmed3f(v1[0][0], v1[0][1], v1[0][2]);
+        const float g2 = __builtin_amdgcn_fmed3f(v0[1][0], v0[1][1], v0[1][2]);
+        const unsigned pm = __float_as_uint(__builtin_amdgcn_fmed3f(g0, g1, g2));
+        const auto pr = __builtin_amdgcn_permlane32_swap(pm, pm, false, false);
+        const unsigned plo = pr[0];                              // (element 0 = the lower half's value in every lane; copied to a
+        piv[t] = __uint_as_float(plo);                           //  scalar first: see half_pair_max in attention.hip)
+      }
       float u1[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};            // this unit's moments: two short chains per k-step, not one of 32
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
@@ -328,8 +341,8 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
           const float d0 = v0[sl][e] - piv[t], d1 = v1[sl][e] - piv[t];
           u1[sl] += d0 + d1;
           u2[sl] = fmaf(d0, d0, fmaf(d1, d1, u2[sl]));
-          fr[e] = from_f32<T>(v0[sl][e]);
-          fr[4 + e] = from_f32<T>(v1[sl][e]);
+          fr[e] = from_f32<T>(d0);                               // the operand is x - pivot: its rounding error scales with the
+          fr[4 + e] = from_f32<T>(d1);                           // row's spread, not with |x| (rows whose mean is far from zero)
         }
         asm volatile("" : "+v"(fr));                           // packed HERE (hipcc otherwise carries the f32 values to the end)
         a[t][2 * cb + sl] = fr;
@@ -357,9 +370,9 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       if (RES && (u & 1) && (u >> 1) + 2 < NUNIT / 2) issue_p((u >> 1) + 2);
     });
     // statistics: this lane holds K/2 elements of each of its RT rows (pivot-shifted moments), lane ^ 32 the other half.
-    // The fragments stay RAW (f16(x): one rounding).  (x - mean) rstd never exists: with sw[col] = sum_k W[col][k] and
-    // sigma = 1 / rstd, out = rstd (acc_raw - mean sw[col] + sigma b[col]) - the bracket's two corrections are ONE fp32 MFMA
-    // (v_mfma_f32_32x32x2_f32: k = 0 multiplies -sw[col] with mean[row], k = 1 b[col] with sigma[row]; exact fp32
+    // The fragments stay UN-normalised (f16(x - pivot): one rounding).  (x - mean) rstd never exists: with sw[col] = sum_k W[col][k]
+    // and sigma = 1 / rstd, out = rstd (acc - (mean - pivot) sw[col] + sigma b[col]) - the bracket's two corrections are ONE fp32 MFMA
+    // (v_mfma_f32_32x32x2_f32: k = 0 multiplies -sw[col] with (mean - pivot)[row], k = 1 b[col] with sigma[row]; exact fp32
     // products) where the plain kernel has its bias k-step, the table aux[col] = (-sw, b) is the caller's
     // (dss_lnlinear_prepare); the epilogue multiplies by rstd.
     constexpr float HN = (float)(LK / 2);
@@ -369,7 +382,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       const float mo = __shfl_xor(mh, 32, 64), m2o = __shfl_xor(m2h, 32, 64);
       const float mean = 0.5f * (mh + mo), dl = mo - mh;
       const float var = (m2h + m2o + dl * dl * (0.5f * HN)) * (1.0f / (float)LK);
-      am[t] = hh ? (var + eps) * rsqrtf(var + eps) : mean;   // A side of the correction k-step: k = 0 mean, k = 1 sigma
+      am[t] = hh ? (var + eps) * rsqrtf(var + eps) : mean - piv[t];   // A side of the correction k-step: k = 0 mean - pivot, k = 1 sigma
     }
     __syncthreads();                                           // the W double buffer returns to its owner
   }
