@@ -104,6 +104,8 @@ def parse():
     ap.add_argument("--no-fuse-k", action="store_true",
                     help="A/B arm: the hooked block's K projection as LayerNorm + library GEMM + dss_kfeatures_finalize "
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
+    ap.add_argument("--fuse-qkv768", action="store_true",
+                    help="D = 768 models: norm1 -> qkv as one dss_lnlinear_k768 launch instead of LayerNorm + library GEMM (A/B arm)")
     ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
                     help="erf = DINO's GELU (default, the reported configuration); tanh_fused = hipBLASLt epilogue "
                          "(tanh approximation, NOT the reference function; diagnostic only)")
@@ -111,6 +113,9 @@ def parse():
                     help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
                          "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
                          "HIP-event durations behind `roofline` then overlap and read long)")
+    ap.add_argument("--tail-overlap", default="auto", choices=["auto", "on", "off"],
+                    help="spectral stage of all forwards but the last on a side stream under the last forward (auto: only for a "
+                         "one-step --dataset shard, where the step's tail is exposed; in the steady state it measured slower)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the spectral stage of sub-batch i on a side stream under the ViT of sub-batch i+1 "
                          "(measured slower on MI355X: both stages are bandwidth-bound; default off)")
@@ -257,22 +262,55 @@ def page_lock(t: torch.Tensor, how: str = "malloc") -> torch.Tensor:
     return t
 
 
-def chunk_counts(cnt: int, vit_batch: int):
-    """Images per ViT forward of a step of ``cnt`` images: forwards of at most ``vit_batch`` images and (nearly) equal size,
-    and at least four of them while they stay above 256 images - the copy of forward j + 1 runs under forward j, so a step
-    that is ONE forward (a 1250-image shard of the 8-GPU run) would wait for all of its bytes before computing anything."""
+ROUND_IMAGES = 0.0   # images whose token rows fill ONE round of the K-resident Linear kernel's workgroups (set in main)
+
+
+def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: float = -1.0):
+    """Images per ViT forward of a step of ``cnt`` images.  A step that is whole forwards of ``vit_batch`` images (the
+    steady state: ``vit_batch`` is sized to whole rounds of workgroups by ``vit.wave_filling_batch``) runs them as they
+    are.  Any other step - a rank's shard of the 8-GPU run: 1250 images = ONE step - is cut so that
+      * every forward but the last is a whole number of ROUNDS of the Linear kernels' workgroups (``round_images`` images
+        fill the 2 x CUs workgroup slots once; round 4 cut 1250 into 4 x 313 = 2.15 rounds each - three rounds of time
+        for 2.15 of work in 51 % of the step's kernels: `lnlinear` 0.213 of peak against 0.239 in the steady state);
+      * there are at least four forwards while they stay above 256 images (the copy of forward j + 1 runs under forward
+        j; a one-forward step would wait for all of its bytes before computing anything);
+      * ``lead``: the FIRST forward of a run is one round only - nothing hides its H2D copy, so it should be short
+        (1250 images: 145 + 436 + 436 + 233, the first copy 100 MB instead of 216 MB)."""
+    rnd = ROUND_IMAGES if round_images < 0 else round_images
+    if cnt % vit_batch == 0 and not (lead and rnd > 0 and cnt == vit_batch):
+        return [vit_batch] * (cnt // vit_batch)
     n = max(1, -(-cnt // vit_batch), min(4, cnt // 256))
-    per, extra = divmod(cnt, n)
-    return [per + (1 if i < extra else 0) for i in range(n)]
+    if rnd <= 0 or cnt < 2 * rnd or n == 1:
+        per, extra = divmod(cnt, n)
+        return [per + (1 if i < extra else 0) for i in range(n)]
+    head = [int(rnd)] if lead else []
+    rest = cnt - sum(head)
+    m = max(1, n - len(head), -(-rest // vit_batch))
+    q = max(1, math.ceil(rest / rnd / m))            # rounds per forward
+    size = min(int(q * rnd), vit_batch)
+    out = list(head)
+    while rest > 0:
+        c = min(size, rest)
+        out.append(c)
+        rest -= c
+    if len(out) > 1 and out[-1] < 32:                # a sliver: fold it into its neighbour
+        out[-2] += out.pop()
+    return out
 
 
-def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fused"):
+_TAIL = {}
+
+
+def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fused", lead=False, tail_overlap=False):
     """One step whose images arrive through the feeder: forward j reads global chunk ``c0 + j``; before it is enqueued the
     copy of the NEXT chunk (this step's, or ``nxt`` = (chunk id, count) of the following step's first) is put on the copy
-    stream.  Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
-    counts = chunk_counts(cnt, vit_batch)
+    stream.  ``tail_overlap`` (a rank's one-step shard): the spectral stage of every forward but the last runs on a side
+    stream UNDER the last forward, so that only the last forward's images are left for the exposed tail of the step.
+    Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
+    counts = chunk_counts(cnt, vit_batch, lead)
     f16 = mode == "fused" and w_dtype == "u16"
     parts, bufs, s0 = [], None, 0
+    early = None
     for j, n in enumerate(counts):
         if j + 1 < len(counts):
             feeder.prefetch(c0 + j + 1, counts[j + 1])
@@ -289,10 +327,29 @@ def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fus
                         torch.empty((cnt, npatch), dtype=torch.float32, device=imgs.device))
             model.extract_k_f16(imgs, out=tuple(b_[s0:s0 + n] for b_ in bufs))
             s0 += n
+            if tail_overlap and len(counts) > 1 and j == len(counts) - 2:
+                # everything up to here (all forwards but the last) goes to the spectral stage NOW, on the side stream
+                main = torch.cuda.current_stream()
+                side = _TAIL.setdefault(imgs.device, torch.cuda.Stream(device=imgs.device))
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    early = (s0, spectral.laplacian_eigs_from_features(bufs[0][:s0], K, strict=False, retry=False, w_dtype=w_dtype,
+                                                                       affinity_mode=mode, feats16=bufs[1][:s0], rnorm=bufs[2][:s0]))
         else:
             parts.append(model.extract_k(imgs))
         feeder.release(c0 + j)
-    if f16:
+    if f16 and early is not None:
+        e0, first = early
+        last = spectral.laplacian_eigs_from_features(bufs[0][e0:], K, strict=False, retry=False, w_dtype=w_dtype,
+                                                     affinity_mode=mode, feats16=bufs[1][e0:], rnorm=bufs[2][e0:])
+        main = torch.cuda.current_stream()
+        main.wait_stream(_TAIL[bufs[0].device])
+        for t in first:
+            t.record_stream(main)
+        out = tuple(torch.cat((a_, b_)) for a_, b_ in zip(first, last))
+    elif f16:
         out = spectral.laplacian_eigs_from_features(bufs[0], K, strict=False, retry=False, w_dtype=w_dtype,
                                                     affinity_mode=mode, feats16=bufs[1], rnorm=bufs[2])
     else:
@@ -447,13 +504,15 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     chunk = first_chunk
-    feeder.prefetch(chunk, chunk_counts(counts[0], a.vit_batch)[0])
+    lead0 = a.dataset > 0            # a rank's shard starts cold: its first forward is one round (see chunk_counts)
+    feeder.prefetch(chunk, chunk_counts(counts[0], a.vit_batch, lead0)[0])
     base = 0
     for s, cnt in enumerate(counts):
-        nchunks = len(chunk_counts(cnt, a.vit_batch))
+        lead = lead0 and s == 0
+        nchunks = len(chunk_counts(cnt, a.vit_batch, lead))
         nxt = (chunk + nchunks, chunk_counts(counts[s + 1], a.vit_batch)[0]) if s + 1 < len(counts) else None
         if a.overlap or a.vit_streams > 1:   # the opt-in variants take a whole step's images at once
-            cc, parts = chunk_counts(cnt, a.vit_batch), []
+            cc, parts = chunk_counts(cnt, a.vit_batch, lead), []
             for j, n in enumerate(cc):        # ring of NBUF buffers: the copy of chunk j + 1 goes out, chunk j is taken
                 if j + 1 < nchunks:           # (cloned: its buffer is handed back before the step reads it), then released
                     feeder.prefetch(chunk + j + 1, cc[j + 1])
@@ -464,7 +523,8 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
             ev, vec, info = step(model, torch.cat(parts) if len(parts) > 1 else parts[0], a.K, a.vit_batch, a.overlap,
                                  a.vit_streams, w_dtype, a.affinity)
         else:
-            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype, a.affinity)
+            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype, a.affinity, lead=lead,
+                                        tail_overlap=a.tail_overlap == "on" or (a.tail_overlap == "auto" and a.dataset > 0 and len(counts) == 1))
         chunk += nchunks
         ids = (torch.arange(cnt, device=dev, dtype=torch.int64) + base) * world + rank   # global round-robin item ids
         base += cnt
@@ -512,7 +572,7 @@ def main():
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
-                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe)
+                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=a.fuse_qkv768)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -523,6 +583,9 @@ def main():
         # launches are paid per forward, HBM (288 GB) is nowhere near a limit (a forward's activations: < 15 GB)
         target = max(8, round(1024 * 901 / (n_patches + 1)))
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
+    global ROUND_IMAGES
+    rows_cu = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
+    ROUND_IMAGES = ncu * rows_cu / (n_patches + 1) if rows_cu and a.linear_kres else 0.0   # see chunk_counts
     if a.batch <= 0:
         # the eigensolver runs one workgroup per image, two per CU: pick the number of ViT forwards per step (4..8: the
         # copy of forward j + 1 hides under forward j) whose image count best fills whole rounds of 2 x CUs workgroups
@@ -548,12 +611,12 @@ def main():
     feeder = ImageFeeder(host, a.vit_batch, dev, resident=a.resident)
     chunk_pos = 0                        # global chunk counter: every warm-up / timed step consumes its own chunks
 
-    def warm_step(m, w_dtype):
-        """One untimed step through the same feeder path as the timed region."""
+    def warm_step(m, w_dtype, lead=False):
+        """One untimed step through the same feeder path as the timed region (``lead``: cut like a run's first step)."""
         nonlocal chunk_pos
-        feeder.prefetch(chunk_pos, chunk_counts(a.batch, a.vit_batch)[0])
+        cc = chunk_counts(a.batch, a.vit_batch, lead)
+        feeder.prefetch(chunk_pos, cc[0])
         if a.overlap or a.vit_streams > 1:
-            cc = chunk_counts(a.batch, a.vit_batch)
             parts = []
             for j, n in enumerate(cc):
                 parts.append(feeder.get(chunk_pos + j, n).clone())
@@ -563,7 +626,8 @@ def main():
             out = step(m, torch.cat(parts), a.K, a.vit_batch, a.overlap, a.vit_streams, w_dtype, a.affinity)
             chunk_pos += len(cc)
             return out
-        ev, vec, info, used = step_fed(m, feeder, chunk_pos, a.batch, None, a.K, a.vit_batch, w_dtype, a.affinity)
+        ev, vec, info, used = step_fed(m, feeder, chunk_pos, a.batch, None, a.K, a.vit_batch, w_dtype, a.affinity, lead=lead,
+                                       tail_overlap=lead and a.tail_overlap != "off" and len(counts) == 1)
         chunk_pos += used
         return ev, vec, info
 
@@ -573,7 +637,8 @@ def main():
     t_warm = time.perf_counter()
     n_warm, warm = 0, None
     while n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warmup_seconds:
-        warm = warm_step(model, a.w_dtype)
+        # a shard run's first step is cut differently (chunk_counts `lead`): warm (and GEMM-tune) both sets of shapes
+        warm = warm_step(model, a.w_dtype, lead=a.dataset > 0 and n_warm % 2 == 0)
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False, use_table=tune)  # frozen for the timed region
@@ -622,7 +687,7 @@ def main():
     if rank == 0:
         kern = summarize_timers(timers, n_patches, dim, depth, a.affinity)
         cands = [k for k in kern if "achieved" in kern[k] and k != "library_gemm"]
-        n_forwards = sum(len(chunk_counts(c, a.vit_batch)) for c in counts)
+        n_forwards = sum(len(chunk_counts(c, a.vit_batch, a.dataset > 0 and i == 0)) for i, c in enumerate(counts))
         steps_out = len(counts)
         roofline = None                      # --timer-sample 0: no kernel was timed, nothing to report
         if cands:
@@ -633,6 +698,12 @@ def main():
                         "unit": d["unit"], "frac": d["frac"], "traffic": traffic[0] if traffic else None,
                         "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE)*1024", "traffic_source": traffic[1] if traffic else None,
                         "timed": f"HIP events around every {max(a.timer_sample, 1)}-th launch inside the timed region"}
+        lib_sites = {}                       # hipBLASLt time per step by call site (events around every --timer-sample-th launch)
+        for st, en, meta in timers.get("library_gemm", []):
+            lib_sites.setdefault(meta.get("what", "?"), []).append(st.elapsed_time(en))
+        n_lib_timed = max(sum(len(v) for v in lib_sites.values()), 1)
+        n_lib_all = timers.get("_launches", {}).get("library_gemm", n_lib_timed)
+        lib_sites = {k_: round(float(np.sum(v)) * n_lib_all / n_lib_timed / steps_out, 3) for k_, v in lib_sites.items()}
         out = {
             "metric": "images/sec end-to-end (features+eigs) at 480², K=5; eigvec cos-err vs CPU",
             "value": round(n_images / elapsed, 2), "unit": "images/s",
@@ -664,7 +735,11 @@ def main():
             # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
             "layernorm_launches_per_forward": round(kern.get("layernorm", {}).get("launches", 0) / max(n_forwards, 1), 2),
             "library_gemm_ms_per_step": round(kern.get("library_gemm", {}).get("total_ms", 0.0) / steps_out, 3),
-            "vit_paths": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k, "fuse_pe": not a.no_fuse_pe},
+            # what each layer of THIS model actually ran on (the switches only apply where a kernel exists for the width /
+            # patch size: round 4's line claimed fuse_k / fuse_pe for dino_vitb8, where neither path exists)
+            "vit_paths": {"switches": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k,
+                                       "fuse_pe": not a.no_fuse_pe, "fuse_qkv768": a.fuse_qkv768}, **model.paths()},
+            "library_gemm_ms_per_step_by_site": lib_sites,
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
             "host_in_loop_ms_per_step": round(host_enqueue_s / steps_out * 1e3, 3),
@@ -683,7 +758,8 @@ def main():
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
-                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe)
+                     fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe,
+                     fuse_qkv768=a.fuse_qkv768)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

@@ -84,7 +84,8 @@ class DinoViT:
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
-                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True):
+                 linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True,
+                 fuse_qkv768: bool = False):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -113,6 +114,10 @@ class DinoViT:
         # inverse norms is ONE kernel (dss_lnlinear_kfeatures_k384) on the pipeline's path (`extract_k_f16`) instead of
         # LayerNorm + library GEMM + dss_kfeatures_finalize
         self.fuse_k = bool(fuse_k)
+        # fuse_qkv768 (D = 768 models, with fuse_ln): norm1 -> qkv as ONE dss_lnlinear_k768 launch instead of the standalone
+        # LayerNorm + the library GEMM.  The one-tile K = 768 kernel is slower than hipBLASLt on the GEMM alone (740-771 vs
+        # 888-932 TF/s) but the pair also moves the normalised activations through HBM twice: A/B'd end to end
+        self.fuse_qkv768 = bool(fuse_qkv768)
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -156,7 +161,7 @@ class DinoViT:
         if self.fuse_ln and self.linear_k384 and d in hip.LINEAR_KRES_WIDTHS:
             for i, blk in enumerate(self.blocks):   # LayerNorm affine folded into the Linear behind it, once per layer
                 p = f"blocks.{i}."
-                if d == 384:
+                if d == 384 or (d == 768 and self.fuse_qkv768):
                     blk["qkv_wg"], blk["qkv_aux"] = hip.lnlinear_prepare(f32(sd[p + "attn.qkv.weight"]), f32(sd[p + "attn.qkv.bias"]),
                                                                          blk["n1w"], blk["n1b"], dtype)
                 if d == 384 and self.fuse_k and dtype == torch.float16:
@@ -173,6 +178,27 @@ class DinoViT:
         if gemm_tuning not in ("table", "online", "off"):
             raise ValueError("gemm_tuning must be 'table' (shipped TunableOp table), 'online' (also tune new shapes) or 'off'")
         setup_gemm_tuning(tune_new_shapes=gemm_tuning == "online", use_table=gemm_tuning != "off")
+
+    def paths(self) -> Dict[str, str]:
+        """Which implementation each layer of a block takes in THIS model (what bench.py reports as `vit_paths`: the
+        constructor's switches only apply where a kernel exists for the width / patch size / dtype)."""
+        blk, d = self.blocks[0], self.embed_dim
+        k384 = bool(self.linear_k384) and d == 384
+        kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
+        lib = "library GEMM (hipBLASLt)"
+        return {
+            "patch_embed": "dss_patch_embed_p16 (transform + GEMM + position rows, one kernel)" if self.pe16 is not None
+                           else f"dss_preprocess_patchify + {lib} + add",
+            "norm1+qkv": f"dss_lnlinear_k{d}" if ("qkv_wg" in blk and self.linear_k384) else
+                         ("dss_layernorm_fwd + dss_linear_k384" if k384 else f"dss_layernorm_fwd + {lib}"),
+            "attention": "dss_attention_fwd",
+            "proj": "dss_linear_k384" if k384 else lib,
+            "norm2+fc1+gelu": f"dss_lnlinear_k{d}" if (kres_fc1 and "fc1_wg" in blk) else
+                              (f"dss_layernorm_fwd + dss_linear_k{d}" if kres_fc1 else f"dss_layernorm_fwd + {lib} + GELU pass"),
+            "fc2": lib,
+            "hooked norm1 + K projection + hand-over": "dss_lnlinear_kfeatures_k384" if "k_wg" in self.blocks[-1] else
+                                                       f"dss_layernorm_fwd + {lib} + dss_kfeatures_finalize",
+        }
 
     # ------------------------------------------------------------------------------------------
     def _pos(self, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -217,18 +243,23 @@ class DinoViT:
         kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
         for i in range(nblocks):
             blk = self.blocks[i]
-            if k384 and "qkv_wg" in blk:      # x += pending; LN1; qkv - one kernel
-                qkv = hip.lnlinear(x, pending, blk["qkv_wg"], blk["qkv_aux"], LN_EPS, planar=True)   # [3h, B*T, 64]
+            qkv_planar = bool(k384)
+            if "qkv_wg" in blk and self.linear_k384:      # x += pending; LN1; qkv - one kernel
+                qkv = hip.lnlinear(x, pending, blk["qkv_wg"], blk["qkv_aux"], LN_EPS, planar=True)   # [3h, B*T, 64]; pending = fc2's row-major output
+                qkv_planar = True
             else:
                 hcur = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
-                qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True) if k384 else \
-                    F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
+                if k384:
+                    qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)
+                else:
+                    with hip._timed("library_gemm", m=b * t, n=3 * d, k=d, what="qkv"):
+                        qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
+            o = hip.attention(qkv, heads, self.scale, planar_bt=(b, t)) if qkv_planar else hip.attention(qkv, heads, self.scale)
             if k384:
-                o = hip.attention(qkv, heads, self.scale, planar_bt=(b, t))
                 pending = hip.linear_kres(o, blk["proj_w"], blk["proj_b"], planar=True)    # [D/64, B*T, 64]
             else:
-                o = hip.attention(qkv, heads, self.scale)
-                pending = F.linear(o, blk["proj_w"], blk["proj_b"])
+                with hip._timed("library_gemm", m=b * t, n=d, k=d, what="proj"):
+                    pending = F.linear(o, blk["proj_w"], blk["proj_b"])
             if kres_fc1 and "fc1_wg" in blk:   # x += pending; LN2; fc1; GELU - one kernel (row-major out: fc2 is a library GEMM)
                 f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=True, residual_planar=bool(k384))
             else:

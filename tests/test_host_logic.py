@@ -146,20 +146,32 @@ def test_synthetic_inputs_are_portable():
 
 
 def test_bench_chunking_is_balanced_and_keeps_the_copy_pipeline_fed():
-    """bench.chunk_counts: forwards of at most vit_batch images, equal to within one image, and at least four per step while
-    they stay above 256 images (a one-forward step cannot hide its H2D copy)."""
+    """bench.chunk_counts: forwards of at most vit_batch images; the steady state runs whole vit_batch forwards; any other step
+    (a rank's shard) is cut into whole ROUNDS of the Linear kernels' workgroups, at least four forwards while they stay above
+    256 images (a one-forward step cannot hide its H2D copy), and a run's FIRST forward is one round (its copy is exposed)."""
     import importlib.util
+    import math
 
     spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.chunk_counts(1250, 1018) == [313, 313, 312, 312]
-    assert bench.chunk_counts(4072, 1018) == [1018] * 4
-    assert bench.chunk_counts(2030, 290) == [290] * 7
-    assert bench.chunk_counts(100, 1018) == [100] and bench.chunk_counts(600, 1018) == [300, 300]
-    for cnt, vb in [(1, 5), (17, 5), (9999, 1018), (873, 291)]:
-        c = bench.chunk_counts(cnt, vb)
-        assert sum(c) == cnt and max(c) <= vb and max(c) - min(c) <= 1
+    rnd = 256 * 512 / 901                                   # dino_vits16 at 480 x 480 on 256 CUs: 145.5 images per round
+    assert bench.chunk_counts(1250, 1018, False, 0.0) == [313, 313, 312, 312]          # no round size known: balanced
+    assert bench.chunk_counts(1250, 1018, True, rnd) == [145, 436, 436, 233]           # BASELINE configs[3]'s per-rank shard
+    assert bench.chunk_counts(1250, 1018, False, rnd) == [436, 436, 378]
+    assert bench.chunk_counts(4072, 1018, False, rnd) == [1018] * 4 == bench.chunk_counts(4072, 1018, True, rnd)
+    assert bench.chunk_counts(2030, 290, False, rnd) == [290] * 7
+    assert bench.chunk_counts(100, 1018, True, rnd) == [100] and bench.chunk_counts(600, 1018, False, 0.0) == [300, 300]
+    for cnt, vb, lead in [(1, 5, False), (17, 5, True), (9999, 1018, False), (873, 291, True), (3334, 1018, True), (1018, 1018, True),
+                          (1251, 1018, True), (700, 1018, False)]:
+        for r in (0.0, rnd):
+            c = bench.chunk_counts(cnt, vb, lead, r)
+            assert sum(c) == cnt and max(c) <= vb and min(c) > 0, (cnt, vb, lead, r, c)
+            if r and cnt >= 2 * r and cnt % vb:
+                rounds = sum(math.ceil(x / r - 1e-9) for x in c)
+                assert rounds <= math.ceil(cnt / r) + 1, (cnt, c, rounds)       # at most one round more than the work itself
+                if lead:
+                    assert c[0] == int(r)
 
 
 def test_wave_filling_batch_picks_whole_waves_of_workgroups():
