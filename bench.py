@@ -113,6 +113,9 @@ def parse():
                     help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
                          "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
                          "HIP-event durations behind `roofline` then overlap and read long)")
+    ap.add_argument("--balanced-chunks", action="store_true",
+                    help="A/B arm: cut a shard step into equal forwards (round 4: 1250 = 4 x 313) instead of whole rounds of "
+                         "workgroups with a one-round lead forward")
     ap.add_argument("--tail-overlap", default="auto", choices=["auto", "on", "off"],
                     help="spectral stage of all forwards but the last on a side stream under the last forward (auto: only for a "
                          "one-step --dataset shard, where the step's tail is exposed; in the steady state it measured slower)")
@@ -585,7 +588,7 @@ def main():
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
     global ROUND_IMAGES
     rows_cu = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
-    ROUND_IMAGES = ncu * rows_cu / (n_patches + 1) if rows_cu and a.linear_kres else 0.0   # see chunk_counts
+    ROUND_IMAGES = ncu * rows_cu / (n_patches + 1) if rows_cu and a.linear_kres and not a.balanced_chunks else 0.0   # see chunk_counts
     if a.batch <= 0:
         # the eigensolver runs one workgroup per image, two per CU: pick the number of ViT forwards per step (4..8: the
         # copy of forward j + 1 hides under forward j) whose image count best fills whole rounds of 2 x CUs workgroups
