@@ -135,7 +135,7 @@ template <int KS, int RT, int NW> struct LinCfg {
 // LNM: 0 = A [M, K] is given;  1 = A = LN(x) without affine;  2 = x += res in place first, then A = LN(x)  (x f32 [M, K];
 // res [M, K] of T, element (r, c) at r * r_ld + (c / 64) * r_plane + c % 64: row-major (K, 64) or DSS_PLANAR64 (64, 64 M)).
 // MODE 0: the Linear layer (output C, row-major or DSS_PLANAR64).
-// MODE 2 (K-feature hand-over, dss_lnlinear_kfeatures_k384): the output of the LAST block's K projection leaves as what the
+// MODE 2 (K-feature hand-over, dss_lnlinear_kfeatures): the output of the LAST block's K projection leaves as what the
 // caller and the affinity build need - token rows b * Tn + t, t >= 1, go to row b * (Tn - 1) + t - 1 of k32 (fp32, straight
 // from the accumulators: 16-byte pieces, a 32-column chunk of a row is one 128-byte line written by one wave), of C = k16
 // (through the transpose patch, as every other output) and rnorm = 1 / max(|k16 row|, eps); CLS rows are computed and dropped.
@@ -600,9 +600,16 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     }
     if constexpr (MODE == 2) {
       // (uniform base in SGPRs + 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic per lane)
+      // The hand-over copy is f16 whatever the operand type T (the affinity build's operands are f16: dss_affinity_f16_u16).
       typedef float f32x4v __attribute__((ext_vector_type(4)));
+      typedef typename vec4<f16>::type H4;
+      typedef typename vec8<f16>::type H8;
       const unsigned half2 = 64u * (c & 1);
       unsigned char* const k32c = reinterpret_cast<unsigned char*>(kf.k32) + (size_t)(c * LBN * 4);      // uniform
+      if constexpr (RT == 1) {                                 // one row tile: the two accumulators are its even / odd k-steps
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+      }
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         const int orow = kf_row(t, eli);
@@ -612,21 +619,21 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
           const f32x4v v = t == 0 ? f32x4v{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]}
                                   : f32x4v{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
           if (orow >= 0) *reinterpret_cast<f32x4v*>(k32c + koff + 32 * g) = v;
-          V4 o;
+          H4 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            o[i] = from_f32<T>(v[i]);
-            const float rr = to_f32<T>(o[i]);
+            o[i] = from_f32<f16>(v[i]);
+            const float rr = to_f32<f16>(o[i]);
             kss[t] = fmaf(rr, rr, kss[t]);
           }
-          *reinterpret_cast<V4*>(stg_w + ((half2 + 16 * g) ^ stg_x) + 4096 * t) = o;
+          *reinterpret_cast<H4*>(stg_w + ((half2 + 16 * g) ^ stg_x) + 4096 * t) = o;
           __builtin_amdgcn_sched_barrier(0);                   // one piece at a time: nothing of the next one is started early
         }
       }
       if (!(c & 1)) return;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read (other lanes' data)
       unsigned char* const k16c = reinterpret_cast<unsigned char*>(C) + (size_t)((c >> 1) * 128);          // uniform
-      // rows rq + 8 i of this wave's 64: at most ONE image boundary among them (Tn > 64, host-checked) - one division
+      // rows rq + 8 i of this wave's 32 RT: at most ONE image boundary among them (Tn > 64, host-checked) - one division
       const unsigned gr0 = (unsigned)blockIdx.x * LBM + (unsigned)__builtin_amdgcn_readfirstlane(rloc) + rq;
       const unsigned b0 = __umulhi(gr0, kmagic);
       const unsigned cls0 = b0 * (unsigned)kf.Tn, cls1 = cls0 + (unsigned)kf.Tn;      // the CLS rows of image b0 and b0 + 1
@@ -636,7 +643,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
         const unsigned gr = gr0 + 8 * i;
         const unsigned off = off0 + (unsigned)(8 * i * LK * 2) - (gr >= cls1 ? (unsigned)(LK * 2) : 0u);
         if ((int)gr < M && gr != cls0 && gr != cls1)
-          *reinterpret_cast<V8*>(k16c + off) = *reinterpret_cast<const V8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i);
+          *reinterpret_cast<H8*>(k16c + off) = *reinterpret_cast<const H8*>(stg + (stg_ro ^ (64u * (i & 1))) + 1024 * i);
       }
       return;
     }
@@ -718,12 +725,13 @@ __global__ __launch_bounds__(512, 1) void patch_embed_kres_kernel(const unsigned
                                              KfOut{x, nullptr, Np, 0.f, img, pos, H, W, Wpat});
 }
 
-// The K = 384 kernel in its hand-over mode (see KfOut): N = 384 output columns, no bias pointer (it rides in aux).
-template <class T, int LNM>
-__global__ __launch_bounds__(256, 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
-                                                            const T* __restrict__ W, const float* __restrict__ aux, T* __restrict__ k16,
+// The kernel in its hand-over mode (see KfOut): N = K output columns, no bias pointer (it rides in aux); k16 is f16 for both T.
+template <class T, int KS, int RT, int NW, int LNM>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
+                                                            const T* __restrict__ W, const float* __restrict__ aux, f16* __restrict__ k16,
                                                             float* __restrict__ k32, float* __restrict__ rnorm, int M, int Tn, float norm_eps) {
-  linear_kres_body<T, false, 24, 2, 4, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, k16, M, 384, 0, KfOut{k32, rnorm, Tn, norm_eps, nullptr, nullptr, 0, 0, 0});
+  linear_kres_body<T, false, KS, RT, NW, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, reinterpret_cast<T*>(k16), M, 16 * KS, 0,
+                                                 KfOut{k32, rnorm, Tn, norm_eps, nullptr, nullptr, 0, 0, 0});
 }
 
 // One wave per output column: Wg[n][k] = T(W[n][k] gamma[k]);  aux[n] = (-sum_k float(Wg[n][k]), bias[n] + sum_k W[n][k] beta[k])
@@ -860,27 +868,44 @@ extern "C" int dss_patch_embed_p16(const uint8_t* img_u8, const void* Wp, const 
   return DSS_OK;
 }
 
+namespace dss {
+template <class T, int KS, int RT, int NW>
+static void launch_kfeat(float* x, const void* residual, long r_ld, long r_plane, float eps, const void* Wg, const float* aux, float* k32,
+                         void* k16, float* rnorm, int M, int T_, float norm_eps, hipStream_t s) {
+  const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
+  if (residual)
+    hipLaunchKernelGGL((kfeat_kres_kernel<T, KS, RT, NW, 2>), dim3(blocks), dim3(64 * NW), 0, s, x, (const T*)residual, r_ld, r_plane, eps,
+                       (const T*)Wg, aux, (f16*)k16, k32, rnorm, M, T_, norm_eps);
+  else
+    hipLaunchKernelGGL((kfeat_kres_kernel<T, KS, RT, NW, 1>), dim3(blocks), dim3(64 * NW), 0, s, x, (const T*)nullptr, r_ld, r_plane, eps,
+                       (const T*)Wg, aux, (f16*)k16, k32, rnorm, M, T_, norm_eps);
+}
+}  // namespace dss
+
+extern "C" int dss_lnlinear_kfeatures(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                                      float* k32, void* k16, float* rnorm, int M, int T, int D, float norm_eps, int dtype, void* stream) {
+  DSS_REQUIRE(x && Wg && aux && k32 && k16 && rnorm, "dss_lnlinear_kfeatures: null pointer");
+  DSS_REQUIRE(D == 384 || D == 768, "dss_lnlinear_kfeatures: D must be 384 or 768 (got %d)", D);
+  DSS_REQUIRE(M > 0 && T > 64 && M % T == 0, "dss_lnlinear_kfeatures: need M = B * T token rows, T > 64 (M=%d T=%d)", M, T);
+  DSS_REQUIRE((long)M * T < 4294967296L && (long)M * D * 4 < 4294967296L,
+              "dss_lnlinear_kfeatures: M=%d x T=%d exceeds the 32-bit row arithmetic of the hand-over epilogue", M, T);
+  DSS_REQUIRE(!residual || res_layout == DSS_ROW_MAJOR || res_layout == DSS_PLANAR64,
+              "dss_lnlinear_kfeatures: res_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", res_layout);
+  DSS_REQUIRE(eps >= 0.f && norm_eps >= 0.f && (const void*)x != residual && (void*)x != (void*)k32, "dss_lnlinear_kfeatures: eps < 0 or aliased buffers");
+  const long r_ld = res_layout == DSS_PLANAR64 ? 64 : D, r_plane = res_layout == DSS_PLANAR64 ? 64L * M : 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DSS_F16 && D == 384) dss::launch_kfeat<dss::f16, 24, 2, 4>(x, residual, r_ld, r_plane, eps, Wg, aux, k32, k16, rnorm, M, T, norm_eps, s);
+  else if (dtype == DSS_F16) dss::launch_kfeat<dss::f16, 48, 1, 8>(x, residual, r_ld, r_plane, eps, Wg, aux, k32, k16, rnorm, M, T, norm_eps, s);
+  else if (dtype == DSS_BF16 && D == 384) dss::launch_kfeat<dss::bf16, 24, 2, 4>(x, residual, r_ld, r_plane, eps, Wg, aux, k32, k16, rnorm, M, T, norm_eps, s);
+  else if (dtype == DSS_BF16) dss::launch_kfeat<dss::bf16, 48, 1, 8>(x, residual, r_ld, r_plane, eps, Wg, aux, k32, k16, rnorm, M, T, norm_eps, s);
+  else return dss::fail(DSS_ERR_BAD_ARG, "dss_lnlinear_kfeatures: dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
+  DSS_CHECK_LAUNCH("dss_lnlinear_kfeatures");
+  return DSS_OK;
+}
+
 extern "C" int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
                                            float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream) {
-  DSS_REQUIRE(x && Wg && aux && k32 && k16 && rnorm, "dss_lnlinear_kfeatures_k384: null pointer");
-  DSS_REQUIRE(M > 0 && T > 64 && M % T == 0, "dss_lnlinear_kfeatures_k384: need M = B * T token rows, T > 64 (M=%d T=%d)", M, T);
-  DSS_REQUIRE((long)M * T < 4294967296L && (long)M * 1536 < 4294967296L,
-              "dss_lnlinear_kfeatures_k384: M=%d x T=%d exceeds the 32-bit row arithmetic of the hand-over epilogue", M, T);
-  DSS_REQUIRE(!residual || res_layout == DSS_ROW_MAJOR || res_layout == DSS_PLANAR64,
-              "dss_lnlinear_kfeatures_k384: res_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", res_layout);
-  DSS_REQUIRE(eps >= 0.f && norm_eps >= 0.f && (const void*)x != residual && (void*)x != (void*)k32, "dss_lnlinear_kfeatures_k384: eps < 0 or aliased buffers");
-  typedef dss::LinCfg<24, 2, 4> Cfg;
-  const long r_ld = res_layout == DSS_PLANAR64 ? 64 : Cfg::K, r_plane = res_layout == DSS_PLANAR64 ? 64L * M : 64;
-  const int blocks = dss::ceil_div(M, Cfg::ROWS);
-  hipStream_t s = (hipStream_t)stream;
-  if (residual)
-    hipLaunchKernelGGL((dss::kfeat_kres_kernel<dss::f16, 2>), dim3(blocks), dim3(256), 0, s, x, (const dss::f16*)residual, r_ld, r_plane, eps,
-                       (const dss::f16*)Wg, aux, (dss::f16*)k16, k32, rnorm, M, T, norm_eps);
-  else
-    hipLaunchKernelGGL((dss::kfeat_kres_kernel<dss::f16, 1>), dim3(blocks), dim3(256), 0, s, x, (const dss::f16*)nullptr, r_ld, r_plane, eps,
-                       (const dss::f16*)Wg, aux, (dss::f16*)k16, k32, rnorm, M, T, norm_eps);
-  DSS_CHECK_LAUNCH("dss_lnlinear_kfeatures_k384");
-  return DSS_OK;
+  return dss_lnlinear_kfeatures(x, residual, res_layout, eps, Wg, aux, k32, k16, rnorm, M, T, 384, norm_eps, DSS_F16, stream);
 }
 
 extern "C" int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,

@@ -40,6 +40,8 @@ SYMBOLS = {
                                   c_int, c_int, c_void_p]),
     "dss_lnlinear_kfeatures_k384": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dss_lnlinear_kfeatures": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dss_patch_embed_p16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dss_affinity_ld": (c_int, [c_int]),
@@ -344,17 +346,17 @@ def lnlinear(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor
 def lnlinear_kfeatures(x: torch.Tensor, residual: Optional[torch.Tensor], wg: torch.Tensor, aux: torch.Tensor, eps: float,
                        norm_eps: float = 1e-12, residual_planar: bool = False, out=None):
     """The hooked block's K projection from the residual stream to the hand-over, in one kernel
-    (``dss_lnlinear_kfeatures_k384``): ``x`` f32 ``[B, T, 384]`` (read only: ``x + residual`` is used, not stored), ``wg, aux`` =
-    ``lnlinear_prepare`` of the K rows of the qkv weight -> ``(k32 [B, T-1, 384] f32, k16 the same in f16, rnorm [B, T-1])``
-    with the CLS row dropped - what ``layernorm`` + a library GEMM + ``kfeatures_finalize`` produce in three passes.
-    ``out``: the three destinations, as for ``kfeatures_finalize``."""
-    assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == 384 and x.is_contiguous()
-    assert wg.dtype == torch.float16 and tuple(wg.shape) == (384, 384) and tuple(aux.shape) == (384, 2)
+    (``dss_lnlinear_kfeatures``): ``x`` f32 ``[B, T, D]``, D = 384 or 768 (read only: ``x + residual`` is used, not stored),
+    ``wg, aux`` = ``lnlinear_prepare`` of the K rows of the qkv weight (f16 or bf16) -> ``(k32 [B, T-1, D] f32, k16 the same in
+    f16 - whatever the operand type -, rnorm [B, T-1])`` with the CLS row dropped - what ``layernorm`` + a library GEMM +
+    ``kfeatures_finalize`` produce in three passes.  ``out``: the three destinations, as for ``kfeatures_finalize``."""
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] in (384, 768) and x.is_contiguous()
     b, t, d = x.shape
+    assert wg.dtype in (torch.float16, torch.bfloat16) and tuple(wg.shape) == (d, d) and tuple(aux.shape) == (d, 2)
     if t <= 64:
         raise ValueError(f"lnlinear_kfeatures: needs more than 64 tokens per image (got {t})")
     if residual is not None:
-        assert residual.dtype == torch.float16 and tuple(residual.shape) == ((d // 64, b * t, 64) if residual_planar else (b, t, d))
+        assert residual.dtype == wg.dtype and tuple(residual.shape) == ((d // 64, b * t, 64) if residual_planar else (b, t, d))
     if out is not None:
         k32, k16, rn = out
         assert tuple(k32.shape) == tuple(k16.shape) == (b, t - 1, d) and tuple(rn.shape) == (b, t - 1)
@@ -364,12 +366,11 @@ def lnlinear_kfeatures(x: torch.Tensor, residual: Optional[torch.Tensor], wg: to
         k16 = torch.empty((b, t - 1, d), dtype=torch.float16, device=x.device)
         rn = torch.empty((b, t - 1), dtype=torch.float32, device=x.device)
     with _timed("lnlinear_kfeatures", m=b * t, n=d, k=d, t=t, res=residual is not None):
-        _check(load_library().dss_lnlinear_kfeatures_k384(
+        _check(load_library().dss_lnlinear_kfeatures(
             _dev(x, "x"), 0 if residual is None else _dev(residual, "residual"), PLANAR64 if residual_planar else ROW_MAJOR,
-            float(eps), _dev(wg, "Wg"), _dev(aux, "aux"), _dev(k32, "k32"), _dev(k16, "k16"), _dev(rn, "rnorm"), b * t, t,
-            float(norm_eps), _stream()), "dss_lnlinear_kfeatures_k384")
+            float(eps), _dev(wg, "Wg"), _dev(aux, "aux"), _dev(k32, "k32"), _dev(k16, "k16"), _dev(rn, "rnorm"), b * t, t, d,
+            float(norm_eps), dtype_code(wg.dtype), _stream()), "dss_lnlinear_kfeatures")
     return k32, k16, rn
-
 
 def linear_k384(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False,
                 planar: bool = False) -> torch.Tensor:

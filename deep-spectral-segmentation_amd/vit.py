@@ -110,8 +110,8 @@ class DinoViT:
             raise ValueError("linear_kres must be 0, 1 or 2")
         self.linear_k384 = int(linear_kres)
         self.fuse_ln = bool(fuse_ln)
-        # fuse_k (default, with fuse_ln, D = 384, f16): the hooked block's norm1 -> K projection -> CLS drop / f16 copy /
-        # inverse norms is ONE kernel (dss_lnlinear_kfeatures_k384) on the pipeline's path (`extract_k_f16`) instead of
+        # fuse_k (default, with fuse_ln): the hooked block's norm1 -> K projection -> CLS drop / f16 copy /
+        # inverse norms is ONE kernel (dss_lnlinear_kfeatures) on the pipeline's path (`extract_k_f16`) instead of
         # LayerNorm + library GEMM + dss_kfeatures_finalize
         self.fuse_k = bool(fuse_k)
         # fuse_qkv768 (D = 768 models, with fuse_ln): norm1 -> qkv as ONE dss_lnlinear_k768 launch instead of the standalone
@@ -164,7 +164,7 @@ class DinoViT:
                 if d == 384 or (d == 768 and self.fuse_qkv768):
                     blk["qkv_wg"], blk["qkv_aux"] = hip.lnlinear_prepare(f32(sd[p + "attn.qkv.weight"]), f32(sd[p + "attn.qkv.bias"]),
                                                                          blk["n1w"], blk["n1b"], dtype)
-                if d == 384 and self.fuse_k and dtype == torch.float16:
+                if self.fuse_k:      # (D = 384 / 768, f16 / bf16: dss_lnlinear_kfeatures; round 4: D = 384 and f16 only)
                     blk["k_wg"], blk["k_aux"] = hip.lnlinear_prepare(blk["k_w32"], blk["k_b32"], blk["n1w"], blk["n1b"], dtype)
                 if self.linear_k384 >= 2 and self.gelu == "erf":
                     blk["fc1_wg"], blk["fc1_aux"] = hip.lnlinear_prepare(f32(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"]),
@@ -196,7 +196,7 @@ class DinoViT:
             "norm2+fc1+gelu": f"dss_lnlinear_k{d}" if (kres_fc1 and "fc1_wg" in blk) else
                               (f"dss_layernorm_fwd + dss_linear_k{d}" if kres_fc1 else f"dss_layernorm_fwd + {lib} + GELU pass"),
             "fc2": lib,
-            "hooked norm1 + K projection + hand-over": "dss_lnlinear_kfeatures_k384" if "k_wg" in self.blocks[-1] else
+            "hooked norm1 + K projection + hand-over": "dss_lnlinear_kfeatures" if "k_wg" in self.blocks[-1] else
                                                        f"dss_layernorm_fwd + {lib} + dss_kfeatures_finalize",
         }
 

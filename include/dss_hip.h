@@ -25,9 +25,9 @@
 extern "C" {
 #endif
 
-/* 6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
+/* 7: + dss_lnlinear_kfeatures (D = 384 / 768, f16 / bf16 operands; round 5);  6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
  * only ever added: a caller built against version n runs against any library with dss_abi_version() >= n. */
-#define DSS_ABI_VERSION 6
+#define DSS_ABI_VERSION 7
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -124,6 +124,11 @@ int dss_lnlinear_k768(float* x, const void* residual, int res_layout, float eps,
  * f16 operands only; 64 < T, M * T < 2^32.  Replaces dss_layernorm_fwd + a library GEMM + dss_kfeatures_finalize. */
 int dss_lnlinear_kfeatures_k384(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
                                 float* k32, void* k16, float* rnorm, int M, int T, float norm_eps, void* stream);
+/* The same hand-over for D = 384 or 768 (dss_lnlinear_k768's body at one row tile per wave) and f16 or bf16 operands (Wg and the
+ * residual are `dtype`; k16 is ALWAYS f16 - what dss_affinity_f16_u16 reads).  M * D * 4 < 2^32.  ABI v7 (round 5): the
+ * D = 768 models' (dino_vitb8 / vitb16) last LayerNorm launch, K-projection GEMM and finalize pass in one kernel. */
+int dss_lnlinear_kfeatures(float* x, const void* residual, int res_layout, float eps, const void* Wg, const float* aux,
+                           float* k32, void* k16, float* rnorm, int M, int T, int D, float norm_eps, int dtype, void* stream);
 
 /* ---- a3 + a5 + a6 (first step): ToTensor + Normalize, the crop to whole patches, DINO's PatchEmbed Conv2d(3, D, 16, 16) and
  * `x = cat(cls, tokens) + pos_embed` for the patch rows, in ONE kernel from the u8 image (extract/extract_utils.py:55-56,

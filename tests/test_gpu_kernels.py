@@ -264,15 +264,17 @@ def test_lnlinear_rejects_bad_arguments():
 
 @pytest.mark.parametrize("b,t", [(2, 901), (1, 197), (3, 65), (5, 130), (1, 3601), (7, 257)])
 @pytest.mark.parametrize("res", [None, "rows", "planar"])
-def test_lnlinear_kfeatures_matches_the_three_kernels_it_replaces(b, t, res):
-    """dss_lnlinear_kfeatures_k384 (x += r; norm1; K projection; CLS drop; f16 copy; inverse norms) against the fp64
-    composition, and against LayerNorm + GEMM + dss_kfeatures_finalize: the fp32 features to the operand-rounding bar of the
-    other fused kernels, k16 = f16(k32) exactly, rnorm = 1 / |k16 row| to fp32 rounding, the residual stream untouched,
-    every output row written (image boundaries fall inside workgroups and inside waves at these shapes)."""
-    k = n = 384
+@pytest.mark.parametrize("k,dtype", [(384, torch.float16), (768, torch.float16), (384, torch.bfloat16), (768, torch.bfloat16)])
+def test_lnlinear_kfeatures_matches_the_three_kernels_it_replaces(b, t, res, k, dtype):
+    """dss_lnlinear_kfeatures (x += r; norm1; K projection; CLS drop; f16 copy; inverse norms; D = 384 / 768, f16 / bf16 operands)
+    against the fp64 composition, and against LayerNorm + GEMM + dss_kfeatures_finalize: the fp32 features to the
+    operand-rounding bar of the other fused kernels, k16 = f16(k32) exactly (f16 whatever the operand type), rnorm =
+    1 / |k16 row| to fp32 rounding, the residual stream untouched, every output row written (image boundaries fall inside
+    workgroups and inside waves at these shapes)."""
+    n = k
     m = b * t
-    x, r, w, bias, gamma, beta = _lnlinear_case(m, n, k, torch.float16, 5 * b + t)
-    wg, aux = hip.lnlinear_prepare(w.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), torch.float16)
+    x, r, w, bias, gamma, beta = _lnlinear_case(m, n, k, dtype, 5 * b + t + k)
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), dtype)
     xd = x.view(b, t, k).to(DEV)
     rd = None if res is None else (_to_planar(r).to(DEV) if res == "planar" else r.view(b, t, k).to(DEV))
     sentinel = 7.0
@@ -286,15 +288,15 @@ def test_lnlinear_kfeatures_matches_the_three_kernels_it_replaces(b, t, res):
         assert bool((u[0] == sentinel).all()) and bool((u[1 + b:] == sentinel).all())
     ref = F.linear(F.layer_norm(xsum.double(), (k,), gamma.double(), beta.double(), 1e-6), w.double(), bias.double())
     ref = ref.view(b, t, n)[:, 1:]
-    tol = 1.5e-3 * max(1.0, ref.abs().max().item())
+    tol = (1.5e-3 if dtype == torch.float16 else 1.2e-2) * max(1.0, ref.abs().max().item())
     assert (k32.cpu().double() - ref).abs().max().item() <= tol
     assert torch.equal(k16, k32.half())
     want_rn = 1.0 / k16.double().norm(dim=-1).clamp_min(1e-12)
     assert ((rn.double() - want_rn).abs() / want_rn).max().item() <= 1e-6
     # the three-kernel path on the same inputs: same quantity, its own roundings
     xb = x.view(b, t, k).to(DEV)
-    h = hip.layernorm(xb, gamma.to(DEV), beta.to(DEV), 1e-6, torch.float16, residual=rd, residual_planar=(res == "planar"))
-    kp = torch.mm(h.view(m, k), w.half().to(DEV).t(), out_dtype=torch.float32).view(b, t, n)
+    h = hip.layernorm(xb, gamma.to(DEV), beta.to(DEV), 1e-6, dtype, residual=rd, residual_planar=(res == "planar"))
+    kp = torch.mm(h.view(m, k), w.to(dtype).to(DEV).t(), out_dtype=torch.float32).view(b, t, n)
     o32, o16, orn = hip.kfeatures_finalize(kp, bias.to(DEV))
     assert (o32.cpu().double() - ref).abs().max().item() <= tol
     assert (k32 - o32).abs().max().item() <= 2 * tol
@@ -312,6 +314,11 @@ def test_lnlinear_kfeatures_rejects_bad_arguments():
     assert f(*ok[:9], 131, 65, 1e-12, s) == -1          # M not a whole number of images
     assert f(*ok[:6], 0, *ok[7:]) == -1                 # no k32
     assert f(*ok[:2], 7, *ok[3:]) == 0                  # (res_layout is not read without a residual)
+    g = lib.dss_lnlinear_kfeatures
+    okg = (*ok[:11], 384, 1e-12, 1, s)
+    assert g(*okg) == 0
+    assert g(*ok[:11], 512, 1e-12, 1, s) == -1          # D must be 384 or 768
+    assert g(*ok[:11], 384, 1e-12, 0, s) == -1          # dtype must be f16 or bf16
     with pytest.raises(ValueError):
         hip.lnlinear_kfeatures(torch.zeros(1, 64, 384, device=DEV), None, wg, aux, 1e-6)
 
