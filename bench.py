@@ -212,7 +212,9 @@ class ImageFeeder:
             return
         self.bufs = [torch.empty((chunk, *host_pool.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(self.NBUF)]
         self.stream = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.ready = [torch.cuda.Event(enable_timing=True) for _ in range(self.NBUF)]
+        self.began = [torch.cuda.Event(enable_timing=True) for _ in range(self.NBUF)]   # (timeline probe: see run_steps)
+        self.log = []                                                                    # (chunk, images, began, ready) per copy
         self.free = [None] * self.NBUF
 
     def prefetch(self, c: int, count: int = 0):
@@ -223,12 +225,17 @@ class ImageFeeder:
         with torch.cuda.stream(self.stream):
             if self.free[b] is not None:
                 self.stream.wait_event(self.free[b])
+            self.began[b] = torch.cuda.Event(enable_timing=True)
+            self.ready[b] = torch.cuda.Event(enable_timing=True)
+            self.began[b].record(self.stream)
             j, off = 0, (c * self.chunk) % self.n
             while j < count:
                 run = min(self.n - off, count - j)
                 self.bufs[b][j:j + run].copy_(self.pool[off:off + run], non_blocking=True)
                 j, off = j + run, (off + run) % self.n
             self.ready[b].record(self.stream)
+            if len(self.log) < 64:
+                self.log.append((c, count, self.began[b], self.ready[b]))
 
     def get(self, c: int, count: int = 0):
         count = count or self.chunk
@@ -506,6 +513,10 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_start.record()
+    if not feeder.resident:
+        feeder.log.clear()
     chunk = first_chunk
     lead0 = a.dataset > 0            # a rank's shard starts cold: its first forward is one round (see chunk_counts)
     feeder.prefetch(chunk, chunk_counts(counts[0], a.vit_batch, lead0)[0])
@@ -539,6 +550,8 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(done)
             host_out[s, :cnt].copy_(flat.view(cnt, width), non_blocking=True)
+    ev_compute = torch.cuda.Event(enable_timing=True)
+    ev_compute.record()                        # the last kernel of the last step (its D2H and the collection follow)
     host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
     # the ONE collection of the run: sizes, then every rank's flat payload point to point to rank 0 (RCCL over xGMI)
     gathered = distributed.gather_records_to_root(torch.cat(metas), torch.cat(flats))
@@ -552,6 +565,11 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
         tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # where the time outside the kernels goes (GPU clock): each H2D copy of the feeder [chunk, images, start, end] relative to
+    # the start of the region, and the end of the last kernel - what follows it is result D2H + collection + synchronisation
+    run_steps.timeline = {"compute_done_ms": round(ev_start.elapsed_time(ev_compute), 3), "elapsed_ms": round(elapsed * 1e3, 3),
+                          "h2d_copies": [] if feeder.resident else
+                          [[c_, n_, round(ev_start.elapsed_time(b_), 3), round(ev_start.elapsed_time(r_), 3)] for c_, n_, b_, r_ in feeder.log[:12]]}
     return elapsed, host_enqueue_s, infos, gathered, chunk
 
 
@@ -675,6 +693,7 @@ def main():
     elapsed, host_enqueue_s, infos, gathered, chunk_pos = run_steps(model, feeder, counts, a, rank, world, n_patches,
                                                                     a.w_dtype, first_chunk=chunk_pos)
     timers, hip.TIMERS = (hip.TIMERS or {}), None
+    timeline = getattr(run_steps, "timeline", None)
     n_images = sum(counts)
     if world > 1:
         tot = torch.tensor([n_images], device=dev, dtype=torch.int64)
@@ -732,7 +751,7 @@ def main():
                        "h2d_in_timed_region": not a.resident, "host_page_lock": {"register": "hipHostRegister", "shm": "hipHostRegister on a /dev/shm segment", "malloc": "hipHostMalloc (tensor.pin_memory)"}[a.host_pin],
                        "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
                        "stage_overlap": a.overlap, "gelu": a.gelu},
-            "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend,
+            "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend, "timeline": timeline,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
             # what is NOT a hand-written kernel, and what the fused prologue removed: standalone LayerNorm launches per ViT
             # forward (23 before round 4; 1 = the last block's norm1 in front of the K projection), hipBLASLt time per step
