@@ -1,8 +1,8 @@
 #!/bin/bash
 # Lab build of the library: one source recompiled with extra flags, linked against the product objects.
 #   scripts/build_lablib.sh <tag> <source.hip> [extra hipcc flags...]   ->  scripts/lablib/libdss_hip_<tag>.so
-# <source.hip> is a file of deep-spectral-segmentation_amd/csrc/, or `linear384_r4_lab.hip` = the round-4 lab snapshot of the Linear kernel in
-# scripts/probes/ (it replaces linear384.o: -DDSS_LIN_LAB_STAGGER, -DDSS_LIN_PLAIN_PREFETCH, -DDSS_LIN_ABL=n, -DDSS_GELU_SCALAR ...).
+# <source.hip> is a file of deep-spectral-segmentation_amd/csrc/, or `linear384_r4_lab.hip` / `attention_r4_lab.hip` = the round-4 lab snapshots of
+# the Linear / attention kernels in scripts/probes/ (it replaces linear384.o: -DDSS_LIN_LAB_STAGGER, -DDSS_LIN_PLAIN_PREFETCH, -DDSS_LIN_ABL=n, -DDSS_GELU_SCALAR ...).
 # (DSS_HIP_LIBRARY=<that file> selects it; the product objects must be current: python deep-spectral-segmentation_amd/build.py)
 set -e
 cd "$(dirname "$0")/.."
@@ -12,6 +12,7 @@ mkdir -p scripts/lablib
 EXTRA=""; [ "$SRC" = attention.hip ] && EXTRA="-fno-honor-nans -mno-amdgpu-ieee"
 PATHSRC=$PKG/csrc/$SRC; REPL=${SRC%.hip}
 if [ "$SRC" = linear384_r4_lab.hip ]; then PATHSRC=scripts/probes/$SRC; REPL=linear384; fi
+if [ "$SRC" = attention_r4_lab.hip ]; then PATHSRC=scripts/probes/$SRC; REPL=attention; EXTRA="-fno-honor-nans -mno-amdgpu-ieee"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA "$@" -c $PATHSRC -o scripts/lablib/${REPL}_$TAG.o
 OBJS=$(ls $PKG/lib/obj/*.o | grep -v "/${REPL}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/lablib/libdss_hip_$TAG.so $OBJS scripts/lablib/${REPL}_$TAG.o

@@ -1,3 +1,6 @@
+// attention_r4_lab.hip - LAB SNAPSHOT of csrc/attention.hip as of round 4 (two partial row sums through v_pk_add_f32, hipcc's
+// ballot sequence, stage-buffer bases added per stage): the A arm of scripts/debug/attn_ab2.py against round 5's kernel.
+// Built by scripts/build_lablib.sh attn_r4 attention_r4_lab.hip; never part of libdss_hip.so.
 // attention.hip - fused multi-head self-attention for the DINO ViT blocks (head dim 64), gfx950 MFMA.
 //
 // Replaces DINO's Attention.forward after the qkv Linear (reached from
@@ -23,8 +26,7 @@
 //   key(r) = (r&3) + 8*(r>>2) + 4*hh,  r = 0..15  of the 32-key block.  Registers 8t..8t+7 (t = 0,1) form
 // the B operand of P.V MFMA number t, i.e. operand slot (hh, e) carries key 16t + 8*(e>>2) + 4*hh + (e&3); the
 // transposed LDS read of V (ds_read_b64_tr_b16) delivers V^T fragments in exactly that key order.
-#include "common.h"
-#include <type_traits>
+#include "../../deep-spectral-segmentation_amd/csrc/common.h"
 #include <utility>
 
 // scripts/probes/attn_lab.hip includes this file with DSS_ATTN_CLOCK defined to read the shader clock the chip sustains
@@ -64,14 +66,6 @@ __device__ __forceinline__ typename vec8<T>::type lds_read_tr_pair(__attribute__
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p_hi));
   const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(typename vec8<T>::type, c);
-}
-
-// K-fragment read / counted wait with the issue order fixed by the source (see `scores` in the kernel)
-template <int OFF, class V> __device__ __forceinline__ void kfrag_read(V& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N, class V> __device__ __forceinline__ void kfrag_wait(V& v) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
 // Cross-half (lane ^ 32) exchange on the VALU (v_permlane32_swap), no LDS round trip: returns, in every lane,
@@ -236,14 +230,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst), "v"(off), "s"(src) : "memory");
   };
-  // (the row offset of the NEXT stage to issue is carried - stages are issued in order - so a stage costs an add and a min, not a
-  //  32-bit multiply: v_mul_lo_u32 is a quarter-rate instruction in a loop where every VALU slot counts)
-  const unsigned dma_max = (unsigned)(Tn - 1) * rb, dma_step = (unsigned)SK * rb;
-  unsigned dma_next = (unsigned)(8 * wave + (lane >> 3)) * rb;
   auto issue = [&](int s) {                                         // wave w moves piece w (8 rows) of K and of V
     const int r = 8 * wave + (lane >> 3);                           // row inside the stage
-    const unsigned rowoff = dma_next < dma_max ? dma_next : dma_max;   // keys past the end: the last key's row (finite data)
-    dma_next += dma_step;
+    int key = s * SK + r;
+    key = key < Tn ? key : Tn - 1;
+    const unsigned rowoff = (unsigned)key * rb;
     const unsigned kc = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
     const unsigned vc = (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s & 1) * 2 * OPB + wave * 1024));
@@ -303,10 +294,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   // end of the sequence are masked through the accumulator's initial value (last halves only).  `first`: no running max
   // yet - straight to the exact path.
   auto half_block = [&](auto bufc, auto halfc, int key0, bool tail, bool first) {
-    // (bufc: std::integral_constant in the paired main loop - the offsets fold into the instructions - or a plain int for the
-    //  odd stage out and the ragged last stage, which run once per workgroup and would only triple the code)
-    const int KOFF = (int)bufc * 2 * OPB + decltype(halfc)::value * 4096;   // K fragments of this half
-    const int VOFF = KOFF + OPB;                                            // V rows of this half
+    constexpr int KOFF = decltype(bufc)::value * 2 * OPB + decltype(halfc)::value * 4096;   // K fragments of this half
+    constexpr int VOFF = KOFF + OPB;                                                        // V rows of this half
     auto scores = [&](bool raw) {          // raw: q.k only (exact path); otherwise q.k - m
       f32x16 s;
       if (tail) {
@@ -316,27 +305,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(*(lds_v8_t)(size_t)(kptr[sl] + KOFF), qf[sl], s);
       } else if (!raw) {
-        // the common path: the four K fragments as a two-deep pipeline pinned in assembly (two reads in flight, counted waits; the
-        // fragment passes through its wait as an operand, which keeps its MFMA behind it).  Left to hipcc the reads of this chain
-        // came out one at a time - read, lgkmcnt(0), MFMA, four times over - once the offsets were immediates.
-        V8 fa, fb;
-        if constexpr (std::is_same<decltype(bufc), int>::value) {
-          kfrag_read<0>(fa, kptr[0] + (unsigned)KOFF); kfrag_read<0>(fb, kptr[1] + (unsigned)KOFF);
-          kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[0], cm);
-          kfrag_read<0>(fa, kptr[2] + (unsigned)KOFF);
-          kfrag_wait<1>(fb); s = mfma32x32x16(fb, qf[1], s);
-          kfrag_read<0>(fb, kptr[3] + (unsigned)KOFF);
-        } else {
-          constexpr int KO = decltype(bufc)::value * 2 * OPB + decltype(halfc)::value * 4096;
-          kfrag_read<KO>(fa, kptr[0]); kfrag_read<KO>(fb, kptr[1]);
-          kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[0], cm);
-          kfrag_read<KO>(fa, kptr[2]);
-          kfrag_wait<1>(fb); s = mfma32x32x16(fb, qf[1], s);
-          kfrag_read<KO>(fb, kptr[3]);
-        }
-        kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[2], s);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb), "+v"(s));   // (tied to the chain: hipcc otherwise hoists it above the third MFMA)
-        s = mfma32x32x16(fb, qf[3], s);
+        s = mfma32x32x16(*(lds_v8_t)(size_t)(kptr[0] + KOFF), qf[0], cm);
+#pragma unroll
+        for (int sl = 1; sl < 4; ++sl) s = mfma32x32x16(*(lds_v8_t)(size_t)(kptr[sl] + KOFF), qf[sl], s);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -436,8 +407,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     full_stage(I0{}, s);
     full_stage(I1{}, s + 1);
   }
-  if (s < nfull) { full_stage(s & 1, s); ++s; }
-  if (s < ns) last_stage(s & 1, s);
+  if (s < nfull) { full_stage(I0{}, s); ++s; }
+  if (s < ns) {
+    if (s & 1) last_stage(I1{}, s);
+    else last_stage(I0{}, s);
+  }
   DSS_CLOCK_END
 
   const float lsum = half_pair_sum(l);                  // the two half-waves hold disjoint keys of each query
@@ -488,7 +462,7 @@ extern "C" int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
   DSS_REQUIRE((long)B * heads * dss::ceil_div(T, 256) < 2147483647L, "dss_attention_fwd: too many workgroups");
   // the DMA addresses rows with 32-bit byte offsets from the (image, head) base
-  DSS_REQUIRE((long)(T + 128) * (qkv_layout == DSS_PLANAR64 ? 128L : 384L * heads) < 4294967296L,   // (+ 128: the carried offset runs one stage ahead)
+  DSS_REQUIRE((long)T * (qkv_layout == DSS_PLANAR64 ? 128L : 384L * heads) < 4294967296L,
               "dss_attention_fwd: T=%d x heads=%d exceeds the 32-bit row offsets of the K/V stage DMA", T, heads);
   hipStream_t s = (hipStream_t)stream;
   const int planar = qkv_layout == DSS_PLANAR64;
