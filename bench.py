@@ -106,9 +106,10 @@ def parse():
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
     ap.add_argument("--fuse-qkv768", action="store_true",
                     help="D = 768 models: norm1 -> qkv as one dss_lnlinear_k768 launch instead of LayerNorm + library GEMM (A/B arm)")
-    ap.add_argument("--gelu", default="erf", choices=["erf", "tanh_fused"],
-                    help="erf = DINO's GELU (default, the reported configuration); tanh_fused = hipBLASLt epilogue "
-                         "(tanh approximation, NOT the reference function; diagnostic only)")
+    ap.add_argument("--gelu", default="erf", choices=["erf", "erf_f16", "tanh_fused"],
+                    help="erf = DINO's GELU evaluated in fp32; erf_f16 = the same function as a polynomial form on packed f16 in "
+                         "fc1's epilogue (f16 operands; error budget: tests/test_host_logic.py::test_gelu_f16_poly_error_budget); "
+                         "tanh_fused = hipBLASLt epilogue (tanh approximation, NOT the reference function; diagnostic only)")
     ap.add_argument("--vit-streams", type=int, default=1,
                     help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
                          "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
@@ -311,11 +312,14 @@ def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: flo
 _TAIL = {}
 
 
-def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fused", lead=False, tail_overlap=False):
+def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fused", lead=False, tail_overlap=False, emit=None):
     """One step whose images arrive through the feeder: forward j reads global chunk ``c0 + j``; before it is enqueued the
     copy of the NEXT chunk (this step's, or ``nxt`` = (chunk id, count) of the following step's first) is put on the copy
     stream.  ``tail_overlap`` (a rank's one-step shard): the spectral stage of every forward but the last runs on a side
     stream UNDER the last forward, so that only the last forward's images are left for the exposed tail of the step.
+    ``emit(first image, eigenvalues, eigenvectors, info)`` is called for every batch of results as soon as its kernels are
+    enqueued, on the stream they run on (the caller packs them and starts their D2H copy there: with ``tail_overlap`` the
+    results of all forwards but the last travel to the host under the last forward too).
     Returns (eigenvalues, eigenvectors, info, chunks consumed)."""
     counts = chunk_counts(cnt, vit_batch, lead)
     f16 = mode == "fused" and w_dtype == "u16"
@@ -347,6 +351,8 @@ def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fus
                     side.wait_event(ready)
                     early = (s0, spectral.laplacian_eigs_from_features(bufs[0][:s0], K, strict=False, retry=False, w_dtype=w_dtype,
                                                                        affinity_mode=mode, feats16=bufs[1][:s0], rnorm=bufs[2][:s0]))
+                    if emit is not None:
+                        emit(0, *early[1])
         else:
             parts.append(model.extract_k(imgs))
         feeder.release(c0 + j)
@@ -354,17 +360,22 @@ def step_fed(model, feeder, c0, cnt, nxt, K, vit_batch, w_dtype="u16", mode="fus
         e0, first = early
         last = spectral.laplacian_eigs_from_features(bufs[0][e0:], K, strict=False, retry=False, w_dtype=w_dtype,
                                                      affinity_mode=mode, feats16=bufs[1][e0:], rnorm=bufs[2][e0:])
+        if emit is not None:
+            emit(e0, *last)
         main = torch.cuda.current_stream()
         main.wait_stream(_TAIL[bufs[0].device])
         for t in first:
             t.record_stream(main)
         out = tuple(torch.cat((a_, b_)) for a_, b_ in zip(first, last))
-    elif f16:
+        return (*out, len(counts))
+    if f16:
         out = spectral.laplacian_eigs_from_features(bufs[0], K, strict=False, retry=False, w_dtype=w_dtype,
                                                     affinity_mode=mode, feats16=bufs[1], rnorm=bufs[2])
     else:
         k = torch.cat(parts) if len(parts) > 1 else parts[0]
         out = spectral.laplacian_eigs_from_features(k, K, strict=False, retry=False, w_dtype=w_dtype, affinity_mode=mode)
+    if emit is not None:
+        emit(0, *out)
     return (*out, len(counts))
 
 
@@ -508,7 +519,7 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
     width = a.K * n_patches + a.K
     host_out = page_lock(torch.empty((len(counts), max(counts), width), dtype=torch.float32), a.host_pin)
     copy_stream = torch.cuda.Stream(device=dev)
-    infos, metas, flats = [], [], []
+    infos, metas, flats, d2h_log = [], [], [], []
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -525,6 +536,24 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
         lead = lead0 and s == 0
         nchunks = len(chunk_counts(cnt, a.vit_batch, lead))
         nxt = (chunk + nchunks, chunk_counts(counts[s + 1], a.vit_batch)[0]) if s + 1 < len(counts) else None
+        def emit(start, ev, vec, info, s=s, base=base):
+            # one batch of results (a whole step, or with --tail-overlap its two parts), on the stream that produced it: pack,
+            # then every rank streams ITS OWN [K, N] results to pinned host memory while the GPU goes on computing
+            n = ev.shape[0]
+            ids = (torch.arange(n, device=dev, dtype=torch.int64) + (base + start)) * world + rank   # global round-robin item ids
+            meta, flat = distributed.pack_records(ids, ev, vec)
+            infos.append(info), metas.append(meta), flats.append(flat)
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                b_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                b_.record(copy_stream)
+                host_out[s, start:start + n].copy_(flat.view(n, width), non_blocking=True)
+                e_.record(copy_stream)
+                flat.record_stream(copy_stream)
+                d2h_log.append((s, start, n, b_, e_))
+
         if a.overlap or a.vit_streams > 1:   # the opt-in variants take a whole step's images at once
             cc, parts = chunk_counts(cnt, a.vit_batch, lead), []
             for j, n in enumerate(cc):        # ring of NBUF buffers: the copy of chunk j + 1 goes out, chunk j is taken
@@ -536,25 +565,18 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
                 feeder.release(chunk + j)
             ev, vec, info = step(model, torch.cat(parts) if len(parts) > 1 else parts[0], a.K, a.vit_batch, a.overlap,
                                  a.vit_streams, w_dtype, a.affinity)
+            emit(0, ev, vec, info)
         else:
-            ev, vec, info, _ = step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype, a.affinity, lead=lead,
-                                        tail_overlap=a.tail_overlap == "on" or (a.tail_overlap == "auto" and a.dataset > 0 and len(counts) == 1))
+            step_fed(model, feeder, chunk, cnt, nxt, a.K, a.vit_batch, w_dtype, a.affinity, lead=lead, emit=emit,
+                     tail_overlap=a.tail_overlap == "on" or (a.tail_overlap == "auto" and a.dataset > 0 and len(counts) == 1))
         chunk += nchunks
-        ids = (torch.arange(cnt, device=dev, dtype=torch.int64) + base) * world + rank   # global round-robin item ids
         base += cnt
-        meta, flat = distributed.pack_records(ids, ev, vec)
-        infos.append(info), metas.append(meta), flats.append(flat)
-        # every rank streams ITS OWN [K, N] results to pinned host memory while the next step computes
-        done = torch.cuda.Event()
-        done.record()
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(done)
-            host_out[s, :cnt].copy_(flat.view(cnt, width), non_blocking=True)
     ev_compute = torch.cuda.Event(enable_timing=True)
     ev_compute.record()                        # the last kernel of the last step (its D2H and the collection follow)
     host_enqueue_s = time.perf_counter() - t0  # host finished enqueueing; the GPU may still be running
     # the ONE collection of the run: sizes, then every rank's flat payload point to point to rank 0 (RCCL over xGMI)
     gathered = distributed.gather_records_to_root(torch.cat(metas), torch.cat(flats))
+    t_gather = time.perf_counter() - t0
     copy_stream.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -568,6 +590,10 @@ def run_steps(model, feeder, counts, a, rank, world, n_patches, w_dtype, first_c
     # where the time outside the kernels goes (GPU clock): each H2D copy of the feeder [chunk, images, start, end] relative to
     # the start of the region, and the end of the last kernel - what follows it is result D2H + collection + synchronisation
     run_steps.timeline = {"compute_done_ms": round(ev_start.elapsed_time(ev_compute), 3), "elapsed_ms": round(elapsed * 1e3, 3),
+                          "host_enqueued_ms": round(host_enqueue_s * 1e3, 3), "collection_returned_ms": round(t_gather * 1e3, 3),
+                          # the result copies [step, first image, images, start, end] (the last ones of the run)
+                          "d2h_copies": [[s_, st_, n_, round(ev_start.elapsed_time(b_), 3), round(ev_start.elapsed_time(e_), 3)]
+                                         for s_, st_, n_, b_, e_ in d2h_log[-3:]],
                           "h2d_copies": [] if feeder.resident else
                           [[c_, n_, round(ev_start.elapsed_time(b_), 3), round(ev_start.elapsed_time(r_), 3)] for c_, n_, b_, r_ in feeder.log[:12]]}
     return elapsed, host_enqueue_s, infos, gathered, chunk

@@ -51,6 +51,7 @@
 //     DSS_LIN_TIMELINE (instrumentation of THIS schedule, scripts/probes/linear_lab.hip); it compiles to nothing in the library.
 #include "common.h"
 #include "kres.h"
+#include <type_traits>
 #include <utility>
 
 // scripts/probes/linear_lab.hip includes this file with DSS_LIN_TIMELINE defined: wave 0 of every workgroup adds the shader
@@ -147,7 +148,7 @@ template <int KS, int RT, int NW> struct LinCfg {
 // pass, no f16 token tensor, no position-embedding pass.  k32 = x, Tn = Np, img / pos / H / W / Wp as named.
 struct KfOut { float* k32; float* rnorm; int Tn; float eps; const unsigned char* img; const float* pos; int H, W, Wp; };
 
-template <class T, bool GELU, int KS, int RT, int NW, int LNM, int MODE>
+template <class T, int GELU, int KS, int RT, int NW, int LNM, int MODE>
 __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float* __restrict__ X,
                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                  const T* __restrict__ W,
@@ -651,7 +652,21 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       unsigned char* wp = stg_w + ((half + 16 * g) ^ stg_x);
-      if (RT == 2) {
+      if constexpr (GELU == 2) {                           // GELU on packed f16 (kres.h): round first, then 5.5 instructions per value
+        static_assert(std::is_same<T, f16>::value, "gelu = 2 is the packed-f16 form: f16 operands only");
+        if (RT == 2) {
+          h2 p[4] = {{(f16)acc0[4 * g], (f16)acc0[4 * g + 1]}, {(f16)acc0[4 * g + 2], (f16)acc0[4 * g + 3]},
+                     {(f16)acc1[4 * g], (f16)acc1[4 * g + 1]}, {(f16)acc1[4 * g + 2], (f16)acc1[4 * g + 3]}};
+          gelu_poly_f16xn<4>(p);
+          *reinterpret_cast<V4*>(wp) = V4{p[0][0], p[0][1], p[1][0], p[1][1]};
+          *reinterpret_cast<V4*>(wp + 4096) = V4{p[2][0], p[2][1], p[3][0], p[3][1]};
+        } else {
+          h2 p[2] = {{(f16)(acc0[4 * g] + acc1[4 * g]), (f16)(acc0[4 * g + 1] + acc1[4 * g + 1])},
+                     {(f16)(acc0[4 * g + 2] + acc1[4 * g + 2]), (f16)(acc0[4 * g + 3] + acc1[4 * g + 3])}};
+          gelu_poly_f16xn<2>(p);
+          *reinterpret_cast<V4*>(wp) = V4{p[0][0], p[0][1], p[1][0], p[1][1]};
+        }
+      } else if (RT == 2) {
         f32x2 v[4] = {{acc0[4 * g], acc0[4 * g + 1]}, {acc0[4 * g + 2], acc0[4 * g + 3]},
                       {acc1[4 * g], acc1[4 * g + 1]}, {acc1[4 * g + 2], acc1[4 * g + 3]}};
         if (GELU) { gelu_erf2xn<LGELU_ILP>(v); if (LGELU_ILP < 4) gelu_erf2xn<LGELU_ILP>(v + 2); }
@@ -707,7 +722,7 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   DSS_TL_FLUSH
 }
 
-template <class T, bool GELU, int KS, int RT, int NW, int LNM, int MODE = 0>
+template <class T, int GELU, int KS, int RT, int NW, int LNM, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void linear_kres_kernel(const T* __restrict__ A, float* __restrict__ X,
                                                                  const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                                  const T* __restrict__ W,
@@ -721,7 +736,7 @@ template <class T>
 __global__ __launch_bounds__(512, 1) void patch_embed_kres_kernel(const unsigned char* __restrict__ img, const T* __restrict__ Wp,
                                                                   const T* __restrict__ biasp, const float* __restrict__ pos,
                                                                   float* __restrict__ x, int M, int N, int Np, int H, int W, int Wpat) {
-  linear_kres_body<T, false, 48, 1, 8, 0, 4>(nullptr, nullptr, nullptr, 0, 0, 0.f, Wp, biasp, nullptr, nullptr, M, N, 0,
+  linear_kres_body<T, 0, 48, 1, 8, 0, 4>(nullptr, nullptr, nullptr, 0, 0, 0.f, Wp, biasp, nullptr, nullptr, M, N, 0,
                                              KfOut{x, nullptr, Np, 0.f, img, pos, H, W, Wpat});
 }
 
@@ -730,7 +745,7 @@ template <class T, int KS, int RT, int NW, int LNM>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void kfeat_kres_kernel(float* __restrict__ X, const T* __restrict__ R, long r_ld, long r_plane, float eps,
                                                             const T* __restrict__ W, const float* __restrict__ aux, f16* __restrict__ k16,
                                                             float* __restrict__ k32, float* __restrict__ rnorm, int M, int Tn, float norm_eps) {
-  linear_kres_body<T, false, KS, RT, NW, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, reinterpret_cast<T*>(k16), M, 16 * KS, 0,
+  linear_kres_body<T, 0, KS, RT, NW, LNM, 2>(nullptr, X, R, r_ld, r_plane, eps, W, nullptr, aux, reinterpret_cast<T*>(k16), M, 16 * KS, 0,
                                                  KfOut{k32, rnorm, Tn, norm_eps, nullptr, nullptr, 0, 0, 0});
 }
 
@@ -761,11 +776,18 @@ template <class T, int KS, int RT, int NW, int LNM, int MODE = 0>
 static void launch_linear_kres(const void* A, float* X, const void* R, long r_ld, long r_plane, float eps, const void* W,
                                const void* bias, const float* aux, void* C, int M, int N, int gelu, int planar, hipStream_t s) {
   const int blocks = ceil_div(M, LinCfg<KS, RT, NW>::ROWS);
+  if constexpr (std::is_same<T, f16>::value) {
+    if (gelu == 2) {
+      hipLaunchKernelGGL((linear_kres_kernel<T, 2, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+                         (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
+      return;
+    }
+  }
   if (gelu)
-    hipLaunchKernelGGL((linear_kres_kernel<T, true, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, 1, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
   else
-    hipLaunchKernelGGL((linear_kres_kernel<T, false, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
+    hipLaunchKernelGGL((linear_kres_kernel<T, 0, KS, RT, NW, LNM, MODE>), dim3(blocks), dim3(64 * NW), 0, s, (const T*)A, X,
                        (const T*)R, r_ld, r_plane, eps, (const T*)W, (const T*)bias, aux, (T*)C, M, N, planar);
 }
 
@@ -776,6 +798,7 @@ static int linear_kres(const char* name, const void* A, float* X, const void* re
                        void* stream) {
   typedef LinCfg<KS, RT, NW> Cfg;
   DSS_REQUIRE((A ? bias != nullptr : (X && aux)) && W && C, "%s: null pointer", name);
+  DSS_REQUIRE(gelu == 0 || gelu == 1 || (gelu == 2 && dtype == DSS_F16), "%s: gelu must be 0, 1 (fp32 erf form) or 2 (packed-f16 form, DSS_F16 only) (got %d)", name, gelu);
   DSS_REQUIRE(M > 0 && N > 0 && N % (2 * LBN) == 0 && N <= Cfg::MAXN, "%s: need M > 0, N %% %d == 0, N <= %d (M=%d N=%d)",
               name, 2 * LBN, Cfg::MAXN, M, N);
   DSS_REQUIRE(out_layout == DSS_ROW_MAJOR || out_layout == DSS_PLANAR64,

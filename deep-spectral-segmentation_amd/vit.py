@@ -95,12 +95,19 @@ class DinoViT:
         self.embed_dim, self.depth, self.num_heads, self.patch_size = VIT_CONFIGS[name]
         self.device, self.dtype = torch.device(device), dtype
         self.k_proj_fp32 = k_proj_fp32
-        if gelu not in ("erf", "tanh_fused"):
-            raise ValueError("gelu must be 'erf' (DINO's exact GELU) or 'tanh_fused'")
+        if gelu not in ("erf", "erf_f16", "tanh_fused"):
+            raise ValueError("gelu must be 'erf' (DINO's exact GELU, fp32 arithmetic), 'erf_f16' (the same function evaluated on "
+                             "packed f16: f16 operands and the K-resident fc1 kernel only) or 'tanh_fused'")
+        if gelu == "erf_f16" and (dtype != torch.float16 or linear_kres < 2 or self.embed_dim not in hip.LINEAR_KRES_WIDTHS):
+            gelu = "erf"        # no packed-f16 epilogue on this path: the fp32 form
         # 'tanh_fused': fc1 + bias + GELU in ONE hipBLASLt launch through the library's epilogue, which implements
         # the TANH approximation (measured: 3.6e-7 from tanh-GELU, 4.7e-4 from erf-GELU).  It is NOT DINO's function:
         # opt-in only, never used for the reported numbers.
+        # 'erf_f16' (round 5): erf-GELU as a degree-6 polynomial form on v_pk_*_f16 in fc1's epilogue (csrc/kres.h: 5.5
+        # instructions per value instead of 17.5, co-issues with the other wave's MFMAs); its error budget against the exact
+        # function over every f16 input is a CPU test (tests/test_host_logic.py::test_gelu_f16_poly_error_budget)
         self.gelu = gelu
+        self._gelu_code = 2 if gelu == "erf_f16" else 1
         # linear_kres: which Linear layers run on the K-resident kernel (dss_linear_k384 / _k768, planar outputs that the
         # attention and LayerNorm kernels read in place).  0: none (library GEMMs: the A/B arm); 1: qkv + proj of the D = 384
         # models; 2 (default): also fc1 with the erf-GELU fused into its epilogue, for D = 384 and D = 768.
@@ -166,7 +173,7 @@ class DinoViT:
                                                                          blk["n1w"], blk["n1b"], dtype)
                 if self.fuse_k:      # (D = 384 / 768, f16 / bf16: dss_lnlinear_kfeatures; round 4: D = 384 and f16 only)
                     blk["k_wg"], blk["k_aux"] = hip.lnlinear_prepare(blk["k_w32"], blk["k_b32"], blk["n1w"], blk["n1b"], dtype)
-                if self.linear_k384 >= 2 and self.gelu == "erf":
+                if self.linear_k384 >= 2 and self.gelu in ("erf", "erf_f16"):
                     blk["fc1_wg"], blk["fc1_aux"] = hip.lnlinear_prepare(f32(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"]),
                                                                          blk["n2w"], blk["n2b"], dtype)
         # final LayerNorm: only the CLS-token path (`forward_cls`, extract_bbox_features) needs it
@@ -184,7 +191,7 @@ class DinoViT:
         constructor's switches only apply where a kernel exists for the width / patch size / dtype)."""
         blk, d = self.blocks[0], self.embed_dim
         k384 = bool(self.linear_k384) and d == 384
-        kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
+        kres_fc1 = self.gelu in ("erf", "erf_f16") and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
         lib = "library GEMM (hipBLASLt)"
         return {
             "patch_embed": "dss_patch_embed_p16 (transform + GEMM + position rows, one kernel)" if self.pe16 is not None
@@ -195,6 +202,8 @@ class DinoViT:
             "proj": "dss_linear_k384" if k384 else lib,
             "norm2+fc1+gelu": f"dss_lnlinear_k{d}" if (kres_fc1 and "fc1_wg" in blk) else
                               (f"dss_layernorm_fwd + dss_linear_k{d}" if kres_fc1 else f"dss_layernorm_fwd + {lib} + GELU pass"),
+            "gelu": {"erf": "exact-erf form in fp32 (A&S 7.1.28, |err| <= 3e-7)", "erf_f16": "erf-GELU polynomial form on packed f16 (csrc/kres.h)",
+                     "tanh_fused": "hipBLASLt's tanh epilogue (NOT the reference function)"}[self.gelu],
             "fc2": lib,
             "hooked norm1 + K projection + hand-over": "dss_lnlinear_kfeatures" if "k_wg" in self.blocks[-1] else
                                                        f"dss_layernorm_fwd + {lib} + dss_kfeatures_finalize",
@@ -240,7 +249,7 @@ class DinoViT:
         # + a separate GELU pass at 16 x 3601 tokens) wins end to end too: dino_vitb8 / C3 689-696 -> 704 images/s on
         # the same box.
         k384 = self.linear_k384 and d == 384
-        kres_fc1 = self.gelu == "erf" and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
+        kres_fc1 = self.gelu in ("erf", "erf_f16") and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
         for i in range(nblocks):
             blk = self.blocks[i]
             qkv_planar = bool(k384)
@@ -261,13 +270,13 @@ class DinoViT:
                 with hip._timed("library_gemm", m=b * t, n=d, k=d, what="proj"):
                     pending = F.linear(o, blk["proj_w"], blk["proj_b"])
             if kres_fc1 and "fc1_wg" in blk:   # x += pending; LN2; fc1; GELU - one kernel (row-major out: fc2 is a library GEMM)
-                f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=True, residual_planar=bool(k384))
+                f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=self._gelu_code, residual_planar=bool(k384))
             else:
                 hcur = hip.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, self.dtype, residual=pending,
                                      residual_planar=bool(k384))
                 if kres_fc1:
-                    f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=True)
-                elif self.gelu == "erf":
+                    f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=self._gelu_code)
+                elif self.gelu in ("erf", "erf_f16"):
                     f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
                 else:
                     f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),

@@ -100,12 +100,14 @@ def test_layernorm_planar_residual_is_bit_identical_to_row_major(res_dtype):
                                    (2 * 3601 + 5, 384, 384), (3601, 2304, 768), (256, 768, 768), (1, 64, 768),
                                    (300, 3072, 768), (513, 128, 768)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("gelu", [False, True, 2])      # 2: the packed-f16 GELU (f16 operands only; same bars as the fp32 form)
 @pytest.mark.parametrize("planar", [False, True])
 def test_linear_kres_matches_fp32_reference(m, n, k, dtype, gelu, planar):
     """The plain PyTorch fp32 op of the same definition (F.linear, then DINO's exact erf GELU) on the same rounded
     operands; tolerance = the output rounding of the half dtype (fp32 accumulation inside).  Shapes cover ragged
     M (not a multiple of the workgroup or the wave tile) and every (N, K) the ViT-S and ViT-B models use."""
+    if gelu == 2 and dtype != torch.float16:
+        pytest.skip("gelu = 2 is the packed-f16 form")
     g = torch.Generator().manual_seed(m + n + k)
     x = torch.randn(m, k, generator=g).to(dtype)
     w = (torch.randn(n, k, generator=g) * 0.05 * (384 / k) ** 0.5).to(dtype)
@@ -123,6 +125,29 @@ def test_linear_kres_matches_fp32_reference(m, n, k, dtype, gelu, planar):
         neg = ref < -0.05
         if neg.any():
             assert (out - ref)[neg].abs().max().item() <= (5e-4 if dtype == torch.float16 else 4e-3)
+
+
+@pytest.mark.parametrize("k", [384, 768])
+def test_gelu_f16_epilogue_is_the_documented_arithmetic_bit_for_bit(k):
+    """`gelu = 2`: with identity weights the accumulator of output (m, n) IS the f16 input A[m][n], so the kernel's output must
+    equal tests.util.gelu_f16_poly (csrc/kres.h restated in numpy, every f16 operation rounding once) on EVERY finite f16 value -
+    the error budget the CPU test states for that arithmetic (tests/test_host_logic.py::test_gelu_f16_poly_error_budget) is
+    then the kernel's.  Also: gelu = 2 is refused for bf16 operands."""
+    from tests.util import gelu_f16_poly
+
+    allh = np.arange(0, 65536, dtype=np.uint16).view(np.float16)
+    vals = allh[np.isfinite(allh)]
+    m = -(-vals.size // k)
+    a = np.zeros(m * k, dtype=np.float16)
+    a[:vals.size] = vals
+    a = torch.from_numpy(a.reshape(m, k))
+    w = torch.eye(k, dtype=torch.float16)
+    out = hip.linear_kres(a.to(DEV), w.to(DEV), torch.zeros(k, dtype=torch.float16, device=DEV), gelu=2).cpu().numpy()
+    with np.errstate(over="ignore"):
+        want = gelu_f16_poly(a.numpy())
+    assert np.array_equal(out, want), int((out != want).sum())    # (values: -0 == +0; for every other finite f16 value == is bit equality)
+    with pytest.raises(hip.HipLibraryError):
+        hip.linear_kres(a.to(DEV).bfloat16(), w.to(DEV).bfloat16(), torch.zeros(k, dtype=torch.bfloat16, device=DEV), gelu=2)
 
 
 @pytest.mark.parametrize("k", [384, 768])
@@ -173,12 +198,14 @@ def _lnlinear_case(m, n, k, dtype, seed, offset=0.5, outliers=False):
 @pytest.mark.parametrize("m,n,k", [(901, 1152, 384), (512, 1536, 384), (1, 64, 384), (77, 384, 384), (1025, 128, 384),
                                    (2 * 901 + 5, 1536, 384), (3601, 3072, 768), (256, 768, 768), (1, 64, 768), (513, 128, 768)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("gelu", [False, True, 2])
 @pytest.mark.parametrize("res", [None, "rows", "planar"])
 def test_lnlinear_matches_fp64_reference(m, n, k, dtype, gelu, res):
     """dss_lnlinear_k384/_k768 against the fp64 composition x += r; LayerNorm(x); Linear; (erf GELU) it replaces.  The
     residual stream must come back as the SAME fp32 sum the standalone LayerNorm pass writes (bit-exact); the output bar is
     the half dtype's output rounding plus the operand rounding of x (|x| <= ~15 sigma here), as for the plain kernel."""
+    if gelu == 2 and dtype != torch.float16:
+        pytest.skip("gelu = 2 is the packed-f16 form")
     x, r, w, b, gamma, beta = _lnlinear_case(m, n, k, dtype, m + n + k + 11)
     wg, aux = hip.lnlinear_prepare(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), dtype)
     xd = x.to(DEV)

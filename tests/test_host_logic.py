@@ -350,3 +350,41 @@ def test_hot_kernels_have_no_register_spills_and_no_scratch():
     src = (REPO / "deep-spectral-segmentation_amd" / "csrc" / "linear384.hip").read_text()
     for lab in ("DSS_LIN_LAB", "DSS_LIN_ABL", "DSS_LINEAR_NO_BARRIER", "DSS_LIN_PLAIN_PREFETCH"):
         assert lab not in src, lab
+
+
+def test_gelu_f16_poly_error_budget():
+    """The packed-f16 GELU of fc1's epilogue (`gelu = 2`, csrc/kres.h; tests/util.gelu_f16_poly is the same arithmetic): its
+    error against the exact erf-GELU over EVERY finite f16 input, next to what the fp32 form delivers (the correctly rounded
+    f16 value).  These are the numbers DESIGN.md quotes as the parity cost of the mode."""
+    from scipy.special import erf
+    from tests.util import gelu_f16_poly
+
+    allh = np.arange(0, 65536, dtype=np.uint16).view(np.float16)
+    xs = allh[np.isfinite(allh)]
+    x64 = xs.astype(np.float64)
+    ref = 0.5 * x64 * (1.0 + erf(x64 / np.sqrt(2.0)))
+    with np.errstate(over="ignore"):
+        y = gelu_f16_poly(xs).astype(np.float64)
+    rounded = ref.astype(np.float16).astype(np.float64)
+    err = np.abs(y - ref)
+    with np.errstate(over="ignore"):
+        spacing = np.abs(np.spacing(ref.astype(np.float16))).astype(np.float64)
+    big = np.abs(x64) > 9                                                  # beyond the polynomial's range the tail term is held at
+    assert np.all(y[big & (x64 > 0)] == x64[big & (x64 > 0)])              # -1.5e-4: x itself for x > 0, -1.5e-4 (exact: ~0) for x < 0
+    assert err[big & (x64 < 0)].max() <= 1.6e-4
+    small = ~big
+    assert err[small].max() <= 1.2e-3 and err[small & (x64 < 0)].max() <= 3.5e-4
+    near0 = (np.abs(x64) < 0.5) & (np.abs(x64) > 1e-4)
+    assert (err[near0] / np.abs(ref[near0])).max() <= 2.2e-3
+    for lo, ulps in ((0.25, 2.1), (0.5, 1.6), (1.0, 1.1), (2.0, 0.6)):     # in units of the OUTPUT's own f16 spacing (a correctly rounded
+        sel = (x64 > lo) & small                                            # value is within 0.5): at most 2.1 above 1/4, 0.6 above 2
+        assert np.all(err[sel] <= ulps * spacing[sel]), lo
+    assert np.mean(y[small] == rounded[small]) >= 0.5                      # more than half of the outputs ARE the correctly rounded value
+
+    def nsr(out, sigma):                                                   # noise / signal for pre-activations ~ N(0, sigma^2)
+        w = np.exp(-0.5 * (x64[small] / sigma) ** 2) * np.abs(np.spacing(xs[small])).astype(np.float64)
+        return float(np.sqrt(np.sum(w * (out[small] - ref[small]) ** 2) / np.sum(w * ref[small] ** 2)))
+
+    for sigma, bar in ((0.7, 1.5), (1.5, 1.15), (3.0, 1.12)):
+        assert nsr(y, sigma) <= bar * nsr(rounded, sigma), (sigma, nsr(y, sigma), nsr(rounded, sigma))
+    assert nsr(y, 1.5) < 2.3e-4 and nsr(rounded, 1.5) > 1.8e-4

@@ -112,3 +112,22 @@ def build_w64(feats):
     d = w.sum(1)
     d[d < 1e-12] = 1.0
     return w, d
+
+
+def gelu_f16_poly(x16):
+    """csrc/kres.h `gelu_poly_f16xn` in numpy, operation for operation (every f16 operation rounds once: products and sums are
+    formed in float64, where they are exact, and rounded to f16): GELU on packed f16 as the Linear kernel's `gelu = 2` epilogue
+    computes it from the f16-rounded pre-activation ``x16``."""
+    import numpy as np
+
+    f16 = np.float16
+    bits = lambda b: np.array(b, dtype=np.uint16).view(f16)[()]
+    x = np.asarray(x16, dtype=f16)
+    x64 = x.astype(np.float64)
+    a = np.minimum(np.abs(x64), 4.25)
+    t = (a * float(bits(0x3388))).astype(f16).astype(np.float64)
+    q = (float(bits(0x3f09)) * t + float(bits(0xc3b6))).astype(f16).astype(np.float64)
+    for c in (0x3c3f, 0x4167, 0xbcb7, 0xbcc0, 0x39a8):
+        q = (q * t + float(bits(c))).astype(f16).astype(np.float64)
+    q = (q * q).astype(f16).astype(np.float64)
+    return (-a * q + np.maximum(x64, 0.0)).astype(f16)
