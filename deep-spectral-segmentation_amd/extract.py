@@ -102,20 +102,39 @@ def _start_method() -> str:
 class _spawn_without_main:
     """``spawn`` children normally re-import the parent's ``__main__`` - a caller's script without an
     ``if __name__ == "__main__"`` guard would then run again inside every I/O worker.  The workers here only need this
-    package (their entry points are ``dss_amd.extract`` functions), so ``__main__`` is hidden from multiprocessing while
-    they are started."""
+    package (their entry points are ``dss_amd.pthfast`` functions), so ``__main__`` is hidden from multiprocessing while
+    they are started.  Re-entrant and thread-safe: the pools grow from helper threads (``_StaggeredPool._grow``) while the
+    main thread may be starting another pool - the first one in hides ``__main__``, the last one out puts it back."""
+
+    _lock = None
+    _depth = 0
+    _saved: dict = {}
 
     def __enter__(self):
-        self.main = sys.modules.get("__main__")
-        self.saved = {a: getattr(self.main, a) for a in ("__file__", "__spec__") if hasattr(self.main, a)}
-        if "__file__" in self.saved:
-            del self.main.__file__
-        if self.main is not None:
-            self.main.__spec__ = None
+        import threading
+
+        cls = _spawn_without_main
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        with cls._lock:
+            if cls._depth == 0:
+                main = sys.modules.get("__main__")
+                cls._saved = {a: getattr(main, a) for a in ("__file__", "__spec__") if hasattr(main, a)}
+                if "__file__" in cls._saved:
+                    del main.__file__
+                if main is not None:
+                    main.__spec__ = None
+            cls._depth += 1
 
     def __exit__(self, *exc):
-        for a, v in self.saved.items():
-            setattr(self.main, a, v)
+        cls = _spawn_without_main
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0:
+                main = sys.modules.get("__main__")
+                for a, v in cls._saved.items():
+                    setattr(main, a, v)
+                cls._saved = {}
 
 
 def _bounded_map(pool: ThreadPoolExecutor, fn, items, window: int):
@@ -132,34 +151,17 @@ def _bounded_map(pool: ThreadPoolExecutor, fn, items, window: int):
 
 
 class _AsyncSaver:
-    """``torch.save`` off the critical path.  Small runs: a thread pool (measured: serial saves of 1.4 MB feature files
-    cap the CLI at ~120 images/s; threads ~210 - pickling and the zip writer hold the GIL).  Large runs
-    (``processes > 0``): worker PROCESSES fed whole batches through shared memory (``submit_batch``), so the per-image
-    pickling runs in parallel; ``close()`` waits for everything and re-raises the first error."""
+    """``torch.save`` off the critical path for SMALL runs: a thread pool (measured: serial saves of 1.4 MB feature files
+    cap the CLI at ~120 images/s; threads ~210 - pickling and the zip writer hold the GIL).  Large runs use ``_FastSaver``
+    (torch-free worker processes).  ``close()`` waits for everything and re-raises the first error."""
 
-    RING = 6   # shared blocks a producer may cycle through (extract_features: features of one batch each)
+    procs = 0   # (no worker processes: what `_FastSaver.procs` is compared with)
 
-    def __init__(self, threads: int = _IO_THREADS, max_pending: int = 1024, processes: int = 0):
+    def __init__(self, threads: int = _IO_THREADS, max_pending: int = 1024):
         self.pool = ThreadPoolExecutor(max_workers=threads)
         self.futures: List = []
         self.waited = 0
         self.max_pending = max_pending
-        self.procs, self.queue, self.errors = [], None, None
-        if processes > 0:
-            import torch.multiprocessing as mp
-
-            ctx = mp.get_context(_start_method())
-            # deep enough that the producer is not held up while the workers are still importing torch
-            self.queue, self.errors = ctx.Queue(maxsize=64 * processes), ctx.Queue()
-            # chunks finished per ring slot (``submit_batch(..., slot=)``): the producer reuses a shared block only
-            # after every chunk cut from its previous contents has been written
-            self.done = [ctx.Value("l", 0) for _ in range(self.RING)]
-            self.sent = [0] * self.RING
-            self.procs = [ctx.Process(target=_pkg._save_worker, args=(self.queue, self.errors, self.done), daemon=True)
-                          for _ in range(processes)]
-            with _spawn_without_main():
-                for p in self.procs:
-                    p.start()
 
     def submit(self, obj, path: str, writer=torch.save):
         self.futures.append(self.pool.submit(writer, obj, path))
@@ -171,36 +173,10 @@ class _AsyncSaver:
 
     def submit_batch(self, kind: str, tensors: Tuple[torch.Tensor, ...], items: List[tuple], chunk: int = 16,
                      slot: Optional[int] = None):
-        """``items`` (one tuple per file, see ``_SAVE_BUILDERS[kind]``) index into the batch ``tensors`` (host tensors;
-        moved to shared memory once per batch).  Without worker processes the files are built here and saved by threads.
-        ``slot``: the tensors live in ring block ``slot`` (``wait_slot`` before overwriting it)."""
-        if not self.procs:
-            for it in items:
-                self.submit(*_SAVE_BUILDERS[kind](tensors, it), writer=_SAVE_WRITERS.get(kind, torch.save))
-            return
-        tensors = tuple(t if t.is_shared() else t.share_memory_() for t in tensors)
-        for s in range(0, len(items), chunk):
-            if slot is not None:
-                self.sent[slot] += 1
-            self._put((kind, tensors, items[s:s + chunk], slot))
-
-    def wait_slot(self, slot: int):
-        """Blocks until the workers have written every file cut from ring block ``slot``."""
-        import time
-        while self.procs and self.done[slot].value < self.sent[slot]:
-            if not all(p.is_alive() for p in self.procs):
-                raise RuntimeError("a saver process died")
-            time.sleep(0.001)
-
-    def _put(self, job):
-        import queue
-
-        while True:   # blocks while the workers are behind - but never on workers that are gone
-            try:
-                return self.queue.put(job, timeout=5)
-            except queue.Full:
-                if not all(p.is_alive() for p in self.procs):
-                    raise RuntimeError("a saver process died") from None
+        """``items`` (one tuple per file, see ``_SAVE_BUILDERS[kind]``) index into the batch ``tensors`` (host tensors): the files
+        are built here and saved by the threads."""
+        for it in items:
+            self.submit(*_SAVE_BUILDERS[kind](tensors, it), writer=_SAVE_WRITERS.get(kind, torch.save))
 
     def close(self):
         for f in self.futures:
@@ -208,18 +184,99 @@ class _AsyncSaver:
         self.futures.clear()
         self.waited = 0
         self.pool.shutdown()
-        if self.procs:
-            for _ in self.procs:
-                self._put(None)
-            for p in self.procs:
-                p.join()
-            failed = [p.exitcode for p in self.procs if p.exitcode != 0]
-            errs = []
-            while not self.errors.empty():
-                errs.append(self.errors.get())
-            self.procs = []
-            if errs or failed:
-                raise RuntimeError(f"saver process failed: {errs[:3] or failed}")
+
+
+class _FastSaver:
+    """The savers of a LARGE run (round 5): torch-free worker processes (``pthfast.save_chunk / save_eigs / save_pngs`` - the
+    archive `torch.save` would write, assembled directly) instead of processes that import torch to call it.  A saver is up
+    in ~0.3 s instead of ~2 s (round 4: first feature file after 3.8 s) and costs a plain interpreter, so there can be
+    dozens: a 1.4 MB feature file is ~2.7 ms of CRC + page-cache copy whoever writes it, and sixteen writers were what
+    capped `extract_features` at ~5 800 images/s (`drain: shared block` = waiting for a ring slot to be written out).
+    Features travel through a ring of page-locked /dev/shm blocks the GPU copies into (``block`` / ``submit_features`` /
+    ``wait_slot``); eigenpairs and label maps are small and go through the pool's pipe (``submit_batch``)."""
+
+    RING = 6
+
+    def __init__(self, processes: int):
+        self.pool = _StaggeredPool(processes)
+        self.procs = processes                       # (truthy, like _AsyncSaver.procs: "worker processes are in use")
+        self.slots = [None] * self.RING              # (path, mmap, u8 tensor, bytes) per ring slot
+        self.pending: List[List] = [[] for _ in range(self.RING + 1)]   # results per slot; [RING] = the pipe jobs
+        self.tag = f"{os.getpid()}_{id(self) & 0xffff:x}"
+
+    def block(self, slot: int, nbytes: int) -> torch.Tensor:
+        """The u8 tensor over ring block ``slot`` (grown if the batch needs more; ``wait_slot`` first)."""
+        import mmap
+
+        cur = self.slots[slot]
+        if cur is None or cur[3] < nbytes:
+            self._free(slot)
+            path = f"/dev/shm/dss_{self.tag}_s{slot}_{nbytes}"
+            fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            try:
+                os.posix_fallocate(fd, 0, nbytes)
+                m = mmap.mmap(fd, nbytes)
+            finally:
+                os.close(fd)
+            t = torch.frombuffer(m, dtype=torch.uint8)
+            try:
+                torch.cuda.cudart().cudaHostRegister(t.data_ptr(), nbytes, 0)
+            except Exception:  # pragma: no cover - pageable copies still work
+                pass
+            self.slots[slot] = cur = (path, m, t, nbytes)
+        return cur[2]
+
+    def _free(self, slot: int):
+        cur, self.slots[slot] = self.slots[slot], None
+        if cur is None:
+            return
+        try:
+            torch.cuda.cudart().cudaHostUnregister(cur[2].data_ptr())
+        except Exception:  # pragma: no cover
+            pass
+        try:
+            os.unlink(cur[0])
+        except OSError:
+            pass
+
+    def submit_features(self, slot: int, items: List[tuple], chunk: int = 8):
+        path, _, _, nbytes = self.slots[slot]
+        for s in range(0, len(items), chunk):
+            self.pending[slot].append(self.pool.apply_async(pthfast.save_chunk, (path, nbytes, "features", items[s:s + chunk])))
+
+    def submit_batch(self, kind: str, tensors: Tuple[torch.Tensor, ...], items: List[tuple], chunk: int = 32, slot=None):
+        """``_AsyncSaver.submit_batch`` for the small kinds: "eigs" (tensors = (eigenvalues [B, K], eigenvectors [B, K, N]), item =
+        (row, out path, problem)) and "png" (tensors = (u8 maps [B, N],), item = (row, out path, rows, cols))."""
+        if kind == "eigs":
+            ev, vec = (t.numpy() for t in tensors)
+            jobs, fn = [(ev[j], vec[j], out) for j, out, _ in items], pthfast.save_eigs
+        elif kind == "png":
+            maps = tensors[0].numpy()
+            jobs, fn = [(maps[j].reshape(hp, wp), out) for j, out, hp, wp in items], pthfast.save_pngs
+        else:
+            raise ValueError(kind)
+        done = self.pending[self.RING]
+        while len(done) > 256:                       # bound the results kept (and surface a worker's error early)
+            done.pop(0).get(timeout=600)
+        for s in range(0, len(jobs), chunk):
+            done.append(self.pool.apply_async(fn, (jobs[s:s + chunk],)))
+
+    def wait_slot(self, slot: int):
+        for r in self.pending[slot]:
+            r.get(timeout=600)                       # re-raises what the worker raised
+        self.pending[slot].clear()
+
+    def close(self):
+        try:
+            for slot in range(self.RING + 1):
+                self.wait_slot(slot)
+            self.pool.__exit__(None, None, None)
+        except BaseException:
+            self.pool.__exit__(RuntimeError, None, None)
+            raise
+        finally:
+            for slot in range(self.RING):
+                self._free(slot)
 
 
 def _build_feature_file(tensors, item):
@@ -248,24 +305,6 @@ def _write_png(arr, path: str):
 
 _SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file, "png": _build_png_file}
 _SAVE_WRITERS = {"png": _write_png}     # everything else: torch.save
-
-
-def _save_worker(queue, errors, done=None):
-    torch.set_num_threads(1)
-    while True:
-        job = queue.get()
-        if job is None:
-            return
-        kind, tensors, items, slot = job
-        try:
-            for it in items:
-                _SAVE_WRITERS.get(kind, torch.save)(*_SAVE_BUILDERS[kind](tensors, it))
-        except BaseException as e:  # reported by close() in the parent
-            errors.put(f"{type(e).__name__}: {e}")
-        del tensors, job
-        if slot is not None:   # also after a failure: the producer must not wait for ever
-            with done[slot].get_lock():
-                done[slot].value += 1
 
 
 class _ShmBlocks:
@@ -406,9 +445,16 @@ class _StaggeredPool:
         self.thread.start()
 
     def _start(self, n: int):
+        with self.lock:
+            if self.closing:                 # (a wave that would start behind __exit__'s back would never be closed)
+                return
         with _spawn_without_main():
             pool = self.ctx.Pool(n)
         with self.lock:
+            if self.closing and self.pools:  # __exit__ has begun meanwhile: this wave is not wanted any more
+                pool.terminate()
+                pool.join()
+                return
             self.pools.append(pool)
             self.load.append(0)
             self.sizes.append(n)
@@ -447,11 +493,14 @@ class _StaggeredPool:
         return self
 
     def __exit__(self, *exc):
-        self.closing = True
-        self.thread.join(timeout=30)
-        for p in self.pools:
+        with self.lock:
+            self.closing = True
+        self.thread.join(timeout=60)         # (its one blocking step is a wave of workers answering their first call)
+        with self.lock:
+            pools = list(self.pools)
+        for p in pools:
             p.terminate() if exc[0] is not None else p.close()
-        for p in self.pools:
+        for p in pools:
             p.join()
         return False
 
@@ -520,31 +569,6 @@ def _iter_images(dataset, todo, processes: int, window: int, device: torch.devic
         release()
 
 
-def _shared_pinned_block(numel: int, dtype: torch.dtype) -> torch.Tensor:
-    """A shared-memory tensor (worker processes map it) that is also page-locked for the GPU's copy engine.  Registration
-    is best effort: without it the copies still work, through the driver's bounce buffers."""
-    t = torch.empty(numel, dtype=dtype).share_memory_()
-    t.zero_()    # touch every page once, here
-    try:
-        rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
-        if int(rc) != 0:
-            print(f"[dss] note: hipHostRegister of a {t.numel() * t.element_size() >> 20} MiB block returned {int(rc)}")
-    except Exception as e:  # pragma: no cover - depends on the runtime
-        print(f"[dss] note: could not page-lock a shared block ({e})")
-    return t
-
-
-def _release_pinned_block(t: Optional[torch.Tensor]) -> None:
-    """Undo ``_shared_pinned_block``'s registration (a block dropped while registered leaves its address range registered:
-    a later registration of reused addresses then fails and the copies fall back to pageable speed)."""
-    if t is None:
-        return
-    try:
-        torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
-    except Exception:  # pragma: no cover - best effort, like the registration
-        pass
-
-
 def _shm_free_bytes() -> int:
     try:
         st = os.statvfs("/dev/shm")
@@ -553,9 +577,11 @@ def _shm_free_bytes() -> int:
         return 0
 
 
-def _io_processes(n_items: int, most: int = 16) -> int:
+def _io_processes(n_items: int, most: int = 16, env: str = "") -> int:
     """Worker processes for the per-image file I/O of a run of ``n_items`` files on this rank: none for small runs,
-    otherwise a share of the host cores, at most ``most`` (``$DSS_IO_PROCESSES`` overrides)."""
+    otherwise a share of the host cores, at most ``most`` (``$DSS_IO_PROCESSES`` overrides every pool, ``$<env>`` this one)."""
+    if env and os.environ.get(env):
+        return int(os.environ[env])
     if os.environ.get("DSS_IO_PROCESSES"):
         return int(os.environ["DSS_IO_PROCESSES"])
     few = 512 if _start_method() == "spawn" else 64   # a spawned interpreter costs ~2 s, a forked one milliseconds
@@ -626,8 +652,9 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
 
     bs = max(1, int(batch_size))
     clock = _StageClock()
-    with clock("start savers"):   # first of all: the saver processes import torch while the model is being built
-        saver = _AsyncSaver(processes=_io_processes(len(todo)))
+    with clock("start savers"):   # first of all: the saver processes boot while the model is being built
+        n_savers = _io_processes(len(todo), most=32, env="DSS_SAVER_PROCESSES")
+        saver = _FastSaver(n_savers) if n_savers > 0 else _AsyncSaver()
     # ~6.5 ms of PIL per 480 x 480 JPEG (150 images/s per process): the ViT takes 12 000 images/s, the feature savers
     # ~1 000 files/s each - dozens of decoders (started in waves of twelve, _StaggeredPool) before the GPU is what waits
     decoders = _io_processes(len(todo), most=48) if saver.procs else 0
@@ -640,7 +667,7 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     # thread is back at the decoded-image queue while the GPU and the drain thread work on the previous batches.
     import queue as _queue
     import threading
-    ring = {"blocks": [None] * _AsyncSaver.RING, "next": 0}
+    ring = {"next": 0}
     copy_stream = torch.cuda.Stream(device=device)
     drain_q: "_queue.Queue" = _queue.Queue(maxsize=3)
     drain_err: List[BaseException] = []
@@ -657,16 +684,13 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                 slot = None
                 with clock("drain: shared block"):
                     if saver.procs:
-                        # a ring of shared-memory blocks the saver processes map, page-locked once: a fresh segment
-                        # per batch cost 90 ms of page faults plus a 1.5 GB/s pageable D2H (177 MB per 128 images)
+                        # a ring of page-locked /dev/shm blocks the saver processes map by path: a fresh segment per batch
+                        # cost 90 ms of page faults plus a 1.5 GB/s pageable D2H (177 MB per 128 images)
                         slot = ring["next"] % saver.RING
                         ring["next"] += 1
-                        saver.wait_slot(slot)
-                        need = k_dev.numel()
-                        if ring["blocks"][slot] is None or ring["blocks"][slot].numel() < need:
-                            _release_pinned_block(ring["blocks"][slot])
-                            ring["blocks"][slot] = _shared_pinned_block(need, k_dev.dtype)
-                        k = ring["blocks"][slot][:need].view(k_dev.shape)
+                        saver.wait_slot(slot)          # every file cut from the block's previous contents has been written
+                        nbytes = k_dev.numel() * k_dev.element_size()
+                        k = saver.block(slot, nbytes)[:nbytes].view(k_dev.dtype).view(k_dev.shape)
                     else:
                         k = torch.empty(k_dev.shape, dtype=k_dev.dtype)
                 with clock("drain: wait + D2H"), torch.cuda.stream(copy_stream):   # not behind the next batch's ViT
@@ -676,7 +700,12 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                     copy_stream.synchronize()
                 del k_dev
                 with clock("drain: hand to savers"):
-                    saver.submit_batch("features", (k,), metas, slot=slot)
+                    if saver.procs:
+                        per = k[0].numel() * k.element_size()
+                        saver.submit_features(slot, [(j * per, tuple(k.shape[1:]), idx, file, mname, psize, shp, out)
+                                                     for j, idx, file, mname, psize, shp, out in metas])
+                    else:
+                        saver.submit_batch("features", (k,), metas)
             except BaseException as e:  # re-raised by the main thread
                 drain_err.append(e)
 
@@ -730,9 +759,6 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
         raise drain_err[0]
     with clock("tail: savers finish"):
         saver.close()
-    for blk in ring["blocks"]:
-        _release_pinned_block(blk)
-    ring["blocks"] = [None] * len(ring["blocks"])
     clock.report("extract_features")
     _barrier()
     print(f"Saved features to {output_dir}")
@@ -942,7 +968,8 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
     nproc = _io_processes(len(mine), most=16)
     clock = _StageClock()
     with clock("start savers"):
-        saver = _AsyncSaver(processes=min(nproc, 4))
+        # (the 'affinity' branch stores its eigenvalues as a raw numpy array - extract.py:171,243 -: `torch.save` on threads)
+        saver = _FastSaver(min(nproc, 8)) if nproc > 0 and which_matrix != "affinity" else _AsyncSaver()
     loaded = _iter_features(mine, which_features, nproc, 4 * bs, device)
     scheduled = set()
     while True:

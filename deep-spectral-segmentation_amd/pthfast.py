@@ -1,5 +1,5 @@
-"""What the I/O worker processes of the two commands run - without torch: the feature-file reader of ``extract_eigs``
-and the image decoder of ``extract_features``.
+"""What the I/O worker processes of the two commands run - without torch: the feature-file reader of ``extract_eigs``,
+the image decoder of ``extract_features`` and (round 5) the WRITER of both commands' ``.pth`` files.
 
 A loader process exists to turn ``<id>.pth`` files (the reference's schema, extract/extract.py:98-110, written by
 ``torch.save``: a ZIP archive of STORED members - ``data.pkl`` plus one raw member per tensor storage) into feature rows
@@ -16,6 +16,7 @@ from __future__ import annotations
 import mmap
 import os
 import pickle
+import struct
 import zipfile
 from collections import OrderedDict
 from typing import Dict, List, Tuple
@@ -233,3 +234,143 @@ def decode_chunk(block_path: str, block_size: int, files: List[str]):
         out.append((used, tuple(img.shape)))
         used += img.size
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The writer (round 5).  A saver process used to `import torch` (1.5-2 s before the first file of a run could be written:
+# "first feature file after 3.8 s", profiles/r04_cli_throughput.txt) to call `torch.save` on tensors it had received
+# through torch's shared-memory pickling.  What `torch.save` writes for the two schemas of this path (extract/extract.py:98-110
+# features, :235,243-244 eigenvectors) is a ZIP of STORED members: `<stem>/data.pkl` - a protocol-2 pickle in which every
+# tensor is `torch._utils._rebuild_tensor_v2(<persistent id of its storage>, offset, size, stride, False, OrderedDict())` -,
+# `<stem>/byteorder`, one raw member `<stem>/data/<n>` per storage and `<stem>/version`.  Those few opcodes are written here
+# directly; the tensor bytes go from the page-locked /dev/shm block the GPU copied them into straight into the archive
+# (`zipfile` computes the CRC on the way).  `torch.load(..., weights_only=True)` reads the result like any other file
+# (tests/test_host_logic.py::test_torch_free_writer_*).
+_STORAGE_NAMES = {np.dtype(v).str: k for k, v in _STORAGE_DTYPES.items()}
+
+
+class TensorOut:
+    """A tensor to be written: a C-contiguous numpy array (any shape, one of the storage dtypes)."""
+
+    def __init__(self, array: np.ndarray):
+        self.array = np.require(array, requirements="C")      # (np.ascontiguousarray would turn a 0-dim array into [1])
+        if self.array.dtype.str not in _STORAGE_NAMES:
+            raise Unsupported(f"tensor dtype {self.array.dtype}")
+
+
+def _pk_int(i: int) -> bytes:
+    if 0 <= i < 256:
+        return b"K" + bytes([i])
+    if 0 <= i < 65536:
+        return b"M" + struct.pack("<H", i)
+    if -2 ** 31 <= i < 2 ** 31:
+        return b"J" + struct.pack("<i", i)
+    raw = i.to_bytes((i.bit_length() + 8) // 8, "little", signed=True)
+    return b"\x8a" + bytes([len(raw)]) + raw
+
+
+def _pk_str(s: str) -> bytes:
+    raw = s.encode("utf-8")
+    return b"X" + struct.pack("<I", len(raw)) + raw
+
+
+def _pk_tuple(items: List[bytes]) -> bytes:
+    if len(items) <= 3:
+        return b"".join(items) + (b")", b"\x85", b"\x86", b"\x87")[len(items)]
+    return b"(" + b"".join(items) + b"t"
+
+
+def _pk_value(v, storages: List[np.ndarray]) -> bytes:
+    if isinstance(v, TensorOut):
+        a = v.array
+        key = str(len(storages))
+        storages.append(a)
+        strides, acc = [], 1
+        for n in reversed(a.shape):
+            strides.append(acc)
+            acc *= n
+        pid = b"(" + _pk_str("storage") + b"ctorch\n" + _STORAGE_NAMES[a.dtype.str].encode() + b"\n" + _pk_str(key) + \
+            _pk_str("cpu") + _pk_int(a.size) + b"t" + b"Q"
+        return b"ctorch._utils\n_rebuild_tensor_v2\n" + b"(" + pid + _pk_int(0) + _pk_tuple([_pk_int(n) for n in a.shape]) + \
+            _pk_tuple([_pk_int(n) for n in reversed(strides)]) + b"\x89" + b"ccollections\nOrderedDict\n" + b")R" + b"t" + b"R"
+    if v is None:
+        return b"N"
+    if v is True or v is False:
+        return b"\x88" if v else b"\x89"
+    if isinstance(v, (int, np.integer)):
+        return _pk_int(int(v))
+    if isinstance(v, (float, np.floating)):
+        return b"G" + struct.pack(">d", float(v))
+    if isinstance(v, str):
+        return _pk_str(v)
+    if isinstance(v, tuple):
+        return _pk_tuple([_pk_value(x, storages) for x in v])
+    if isinstance(v, dict):
+        body = b"".join(_pk_value(k, storages) + _pk_value(x, storages) for k, x in v.items())
+        return b"}" + (b"(" + body + b"u" if v else b"")
+    raise Unsupported(f"cannot write a {type(v).__name__}")
+
+
+def dumps_pth(obj) -> Tuple[bytes, List[np.ndarray]]:
+    """``(data.pkl bytes, storages in key order)`` for ``obj``: nested dicts / tuples of str, int, float, bool, None and
+    ``TensorOut`` (every tensor gets its own storage, like tensors that share none in ``torch.save``)."""
+    storages: List[np.ndarray] = []
+    body = _pk_value(obj, storages)
+    return b"\x80\x02" + body + b".", storages
+
+
+def write_pth(path: str, obj) -> None:
+    """``torch.save(obj, path)`` for the object kinds ``dumps_pth`` knows, without torch.  Written to ``path + '.tmp'`` and renamed:
+    a killed run leaves no half-written file behind for the next run's skip-if-exists to trust."""
+    pkl, storages = dumps_pth(obj)
+    stem = os.path.splitext(os.path.basename(path))[0] or "archive"
+    tmp = f"{path}.tmp{os.getpid()}"
+    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED, allowZip64=True) as z:
+        z.writestr(f"{stem}/data.pkl", pkl)
+        z.writestr(f"{stem}/byteorder", b"little")
+        for i, a in enumerate(storages):
+            with z.open(f"{stem}/data/{i}", "w", force_zip64=a.nbytes >= (1 << 31)) as fh:
+                fh.write(memoryview(a).cast("B") if a.size else b"")
+        z.writestr(f"{stem}/version", b"3\n")
+    os.replace(tmp, path)
+
+
+def save_chunk(block_path: str, block_size: int, kind: str, items: list):
+    """Worker entry of both commands' savers: the tensors of ``items`` lie in the shared block (the GPU copied them there).
+    ``kind == "features"``: item = (byte offset, (N, D), index, file, model_name, patch_size, shape, out path) -> the reference's
+    feature dict (extract/extract.py:98-110: ``k`` [1, N, D] f32, ``indices`` a 0-dim int64 tensor, ...).
+    ``kind == "eigs"``: item = (offset of the [K, N] f32 eigenvectors, offset of the [K] f32 eigenvalues, K, N, out path) ->
+    ``{"eigenvalues", "eigenvectors"}`` (:235,243-244).  Returns the number of files written."""
+    buf = _block(block_path, block_size)
+    for it in items:
+        if kind == "features":
+            off, (n, d), index, file, model_name, patch_size, shape, out = it
+            k = np.frombuffer(buf, dtype=np.float32, count=n * d, offset=off).reshape(1, n, d)
+            write_pth(out, {"k": TensorOut(k), "indices": TensorOut(np.array(index, dtype=np.int64)), "file": file,
+                            "id": os.path.splitext(os.path.basename(file))[0], "model_name": model_name,
+                            "patch_size": int(patch_size), "shape": tuple(int(v) for v in shape)})
+        elif kind == "eigs":
+            voff, eoff, kk, n, out = it
+            vec = np.frombuffer(buf, dtype=np.float32, count=kk * n, offset=voff).reshape(kk, n)
+            val = np.frombuffer(buf, dtype=np.float32, count=kk, offset=eoff)
+            write_pth(out, {"eigenvalues": TensorOut(val), "eigenvectors": TensorOut(vec)})
+        else:
+            raise ValueError(kind)
+    return len(items)
+
+
+def save_eigs(items: list):
+    """Worker entry: ``items`` = ``(eigenvalues [K] f32 array, eigenvectors [K, N] f32 array, out path)`` per image (18 KB per
+    image: the arrays travel through the pool's pipe, no shared block) -> the reference's eigen dict (extract/extract.py:235,243-244)."""
+    for val, vec, out in items:
+        write_pth(out, {"eigenvalues": TensorOut(np.asarray(val, np.float32)), "eigenvectors": TensorOut(np.asarray(vec, np.float32))})
+    return len(items)
+
+
+def save_pngs(items: list):
+    """Worker entry: ``(u8 [rows, cols] label / mask map, out path)`` per image -> one 8-bit PNG (extract/extract.py:352,405)."""
+    from PIL import Image
+
+    for arr, out in items:
+        Image.fromarray(np.asarray(arr, np.uint8)).save(out)
+    return len(items)

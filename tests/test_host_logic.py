@@ -1,4 +1,5 @@
 """CPU: host-side logic of the drop-in boundary (no kernels run)."""
+import os
 import re
 from pathlib import Path
 
@@ -252,25 +253,46 @@ def test_dataset_applies_exif_orientation_like_cv2(tmp_path):
 
 
 def test_file_io_worker_processes_round_trip(tmp_path):
-    """Large CLI runs hand whole batches to saver / loader PROCESSES through shared memory (extract._AsyncSaver,
-    extract._iter_features): same files as the in-process path, errors surfaced by close()."""
+    """Large CLI runs hand whole batches to torch-free saver / loader PROCESSES (extract._FastSaver through page-locked
+    /dev/shm blocks and the pool's pipe, extract._iter_features): same files as the in-process path, loadable with
+    `torch.load(weights_only=True)`, errors surfaced by wait_slot() / close()."""
     k = torch.randn(5, 12, 8)
     items = [(j, 100 + j, f"im_{j}.jpg", "dino_vits16", 16, (1, 3, 48, 64), str(tmp_path / f"im_{j}.pth")) for j in range(5)]
-    saver = extract._AsyncSaver(processes=2)
-    saver.submit_batch("features", (k.clone(),), items, chunk=2)
+    saver = extract._FastSaver(2)
+    blk = saver.block(1, k.numel() * 4)
+    blk[:k.numel() * 4].view(torch.float32).view(k.shape).copy_(k)
+    saver.submit_features(1, [(j * 12 * 8 * 4, (12, 8), idx, file, m, p, shp, out) for j, idx, file, m, p, shp, out in items], chunk=2)
     ev, vec = torch.randn(5, 3), torch.randn(5, 3, 12)
     (tmp_path / "e").mkdir()
-    saver.submit_batch("eigs", (ev.clone(), vec.clone()), [(j, str(tmp_path / "e" / f"im_{j}.pth"), "laplacian" if j else "affinity")
-                                                           for j in range(5)])
+    saver.submit_batch("eigs", (ev.clone(), vec.clone()), [(j, str(tmp_path / "e" / f"im_{j}.pth"), "laplacian") for j in range(5)])
+    labels = (torch.arange(5 * 12).reshape(5, 12) % 7).to(torch.uint8)
+    saver.submit_batch("png", (labels,), [(j, str(tmp_path / "e" / f"im_{j}.png"), 3, 4) for j in range(5)])
+    saver.wait_slot(1)
     saver.close()
+    from PIL import Image
     for j in range(5):
         d = torch.load(tmp_path / f"im_{j}.pth", weights_only=True)
-        assert torch.equal(d["k"], k[j:j + 1]) and int(d["indices"]) == 100 + j and d["id"] == f"im_{j}"
+        want = extract._feature_dict(k[j:j + 1], 100 + j, f"im_{j}.jpg", "dino_vits16", 16, (1, 3, 48, 64))
+        assert set(d) == set(want) and all(type(d[key]) is type(want[key]) for key in want)     # the reference's schema, key for key
+        assert torch.equal(d["k"], k[j:j + 1]) and d["k"].dtype == torch.float32 and tuple(d["k"].shape) == (1, 12, 8)
+        assert d["indices"].dtype == torch.int64 and d["indices"].dim() == 0 and int(d["indices"]) == 100 + j
+        assert d["id"] == f"im_{j}" and d["file"] == f"im_{j}.jpg" and d["shape"] == (1, 3, 48, 64) and d["patch_size"] == 16
         assert d["k"].untyped_storage().nbytes() == 12 * 8 * 4          # one image per file, not the whole batch
-        e = torch.load(tmp_path / "e" / f"im_{j}.pth", weights_only=False)
-        assert torch.equal(e["eigenvectors"], vec[j]) and np.array_equal(np.asarray(e["eigenvalues"]), ev[j].numpy())
-        assert isinstance(e["eigenvalues"], np.ndarray) == (j == 0)
-    # mixed shapes through the loader processes, every file exactly once
+        e = torch.load(tmp_path / "e" / f"im_{j}.pth", weights_only=True)
+        assert set(e) == {"eigenvalues", "eigenvectors"} and torch.equal(e["eigenvectors"], vec[j]) and torch.equal(e["eigenvalues"], ev[j])
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "e" / f"im_{j}.png")), labels[j].reshape(3, 4).numpy())
+    assert not list(tmp_path.glob("*.tmp*")) and not [n for n in os.listdir("/dev/shm") if n.startswith(f"dss_{os.getpid()}_")]
+    # the small-run path (threads, torch.save) writes the same dicts - including the 'affinity' branch's numpy eigenvalues
+    small = extract._AsyncSaver()
+    (tmp_path / "s").mkdir()
+    small.submit_batch("features", (k,), [(*it[:6], str(tmp_path / "s" / f"im_{it[0]}.pth")) for it in items])
+    small.submit_batch("eigs", (ev, vec), [(0, str(tmp_path / "s" / "aff.pth"), "affinity")])
+    small.close()
+    for j in range(5):
+        a, b = (torch.load(tmp_path / sub / f"im_{j}.pth", weights_only=True) for sub in (".", "s"))
+        assert all(torch.equal(a[key], b[key]) if torch.is_tensor(a[key]) else a[key] == b[key] for key in a)
+    assert isinstance(torch.load(tmp_path / "s" / "aff.pth", weights_only=False)["eigenvalues"], np.ndarray)
+    # mixed shapes through the loader processes, every file exactly once (files written by BOTH writers)
     torch.save({"k": torch.randn(1, 7, 8), "file": "odd.jpg", "id": "odd", "patch_size": 16, "shape": (1, 3, 16, 112),
                 "indices": torch.tensor(9), "model_name": "m"}, tmp_path / "zz_odd.pth")
     files = sorted(p for p in tmp_path.iterdir() if p.suffix == ".pth")
@@ -278,10 +300,42 @@ def test_file_io_worker_processes_round_trip(tmp_path):
     ref = {d["id"]: f for d, f in extract._iter_features(files, "k", 0, 8)}
     assert set(got) == set(ref) == {f"im_{j}" for j in range(5)} | {"odd"}
     assert all(torch.equal(got[i], ref[i]) for i in got) and got["odd"].shape == (7, 8)
-    bad = extract._AsyncSaver(processes=1)
-    bad.submit_batch("features", (k.clone(),), [(0, 0, "x.jpg", "m", 16, (1, 3, 4, 4), str(tmp_path / "no_dir" / "x.pth"))])
-    with pytest.raises(RuntimeError):
+    bad = extract._FastSaver(1)
+    bad.block(0, 64)
+    bad.submit_features(0, [(0, (2, 2), 0, "x.jpg", "m", 16, (1, 3, 4, 4), str(tmp_path / "no_dir" / "x.pth"))])
+    with pytest.raises(Exception):
         bad.close()
+
+
+def test_torch_free_writer_matches_torch_save_for_both_schemas(tmp_path):
+    """pthfast.write_pth (what the saver processes run instead of `import torch; torch.save`): for the feature and eigen schemas
+    the archive loads with `torch.load(weights_only=True)` to exactly what torch.save's own file loads to - same keys, Python
+    types, dtypes, shapes, values (0-dim int64 `indices`, a non-ASCII file name, an id above 2^31) - and with the torch-free
+    READER of `extract_eigs` as well."""
+    from dss_amd import pthfast
+
+    k = torch.randn(1, 30, 16)
+    want = extract._feature_dict(k, 2 ** 33 + 5, "sub dir/bild_ä.jpg", "dino_vitb8", 8, (1, 3, 40, 48))
+    torch.save(want, tmp_path / "ref.pth")
+    pthfast.write_pth(str(tmp_path / "fast.pth"), {
+        "k": pthfast.TensorOut(k.numpy()), "indices": pthfast.TensorOut(np.array(2 ** 33 + 5, dtype=np.int64)),
+        "file": "sub dir/bild_ä.jpg", "id": "bild_ä", "model_name": "dino_vitb8", "patch_size": 8, "shape": (1, 3, 40, 48)})
+    a, b = (torch.load(tmp_path / n, weights_only=True) for n in ("ref.pth", "fast.pth"))
+    assert list(a) == list(b)
+    for key in a:
+        assert type(a[key]) is type(b[key]), key
+        if torch.is_tensor(a[key]):
+            assert a[key].dtype == b[key].dtype and a[key].shape == b[key].shape and torch.equal(a[key], b[key]), key
+        else:
+            assert a[key] == b[key], key
+    with pthfast.PthFile(str(tmp_path / "fast.pth")) as f:
+        assert np.array_equal(f.read(f.obj["k"]), k.numpy()) and int(f.read(f.obj["indices"])) == 2 ** 33 + 5
+    ev, vec = torch.randn(4), torch.randn(4, 30)
+    pthfast.save_eigs([(ev.numpy(), vec.numpy(), str(tmp_path / "eig.pth"))])
+    e = torch.load(tmp_path / "eig.pth", weights_only=True)
+    assert list(e) == ["eigenvalues", "eigenvectors"] and torch.equal(e["eigenvalues"], ev) and torch.equal(e["eigenvectors"], vec)
+    with pytest.raises(pthfast.Unsupported):
+        pthfast.dumps_pth({"x": [1, 2]})
 
 
 def test_integration_md_binding_stub_matches_the_declared_abi():
