@@ -106,9 +106,10 @@ def parse():
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
     ap.add_argument("--fuse-qkv768", action="store_true",
                     help="D = 768 models: norm1 -> qkv as one dss_lnlinear_k768 launch instead of LayerNorm + library GEMM (A/B arm)")
-    ap.add_argument("--gelu", default="erf", choices=["erf", "erf_f16", "tanh_fused"],
-                    help="erf = DINO's GELU evaluated in fp32; erf_f16 = the same function as a polynomial form on packed f16 in "
-                         "fc1's epilogue (f16 operands; error budget: tests/test_host_logic.py::test_gelu_f16_poly_error_budget); "
+    ap.add_argument("--gelu", default="erf_f16", choices=["erf", "erf_f16", "tanh_fused"],
+                    help="erf_f16 (default, = DinoViT's) = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
+                         "operands; error budget: tests/test_host_logic.py::test_gelu_f16_poly_error_budget; bf16 falls back to erf); "
+                         "erf = the same function evaluated in fp32 (the A/B arm: +3.9 %% step time); "
                          "tanh_fused = hipBLASLt epilogue (tanh approximation, NOT the reference function; diagnostic only)")
     ap.add_argument("--vit-streams", type=int, default=1,
                     help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
@@ -285,8 +286,9 @@ def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: flo
         for 2.15 of work in 51 % of the step's kernels: `lnlinear` 0.213 of peak against 0.239 in the steady state);
       * there are at least four forwards while they stay above 256 images (the copy of forward j + 1 runs under forward
         j; a one-forward step would wait for all of its bytes before computing anything);
-      * ``lead``: the FIRST forward of a run is one round only - nothing hides its H2D copy, so it should be short
-        (1250 images: 145 + 436 + 436 + 233, the first copy 100 MB instead of 216 MB)."""
+      * ``lead``: the FIRST forward of a run is short - nothing hides its H2D copy - and takes the step's fractional round
+        (1250 images = 8.59 rounds: 88 + 436 + 436 + 290 = 0.6 + 3 + 3 + 2 rounds, the first copy 61 MB instead of 216 MB;
+        a partly filled round costs a whole round's time wherever it is, and at the front it is also the shortest copy)."""
     rnd = ROUND_IMAGES if round_images < 0 else round_images
     if cnt % vit_batch == 0 and not (lead and rnd > 0 and cnt == vit_batch):
         return [vit_batch] * (cnt // vit_batch)
@@ -294,19 +296,19 @@ def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: flo
     if rnd <= 0 or cnt < 2 * rnd or n == 1:
         per, extra = divmod(cnt, n)
         return [per + (1 if i < extra else 0) for i in range(n)]
-    head = [int(rnd)] if lead else []
-    rest = cnt - sum(head)
-    m = max(1, n - len(head), -(-rest // vit_batch))
-    q = max(1, math.ceil(rest / rnd / m))            # rounds per forward
-    size = min(int(q * rnd), vit_batch)
-    out = list(head)
-    while rest > 0:
-        c = min(size, rest)
-        out.append(c)
-        rest -= c
-    if len(out) > 1 and out[-1] < 32:                # a sliver: fold it into its neighbour
-        out[-2] += out.pop()
-    return out
+    total = cnt / rnd
+    whole, frac = math.floor(total), total - math.floor(total)
+    if lead:      # the lead forward takes what the whole rounds leave: `frac` of a round, or 1 + frac if that would be a sliver
+        body, m = (whole if frac >= 1.0 / 3.0 else whole - 1), max(1, n - 1)
+    else:
+        body, m = math.ceil(total), n
+    m = min(max(m, -(-body // max(1, math.floor(vit_batch / rnd)))), body)     # <= vit_batch images and >= one round per forward
+    rounds = [body // m + (1 if i < body % m else 0) for i in range(m)]
+    sizes = [math.floor(r * rnd) for r in rounds]
+    if lead:
+        return [cnt - sum(sizes)] + sizes
+    sizes[-1] = cnt - sum(sizes[:-1])
+    return sizes
 
 
 _TAIL = {}
@@ -689,14 +691,15 @@ def main():
         torch.cuda.synchronize()
         n_warm += 1
     setup_gemm_tuning(tune_new_shapes=False, use_table=tune)  # frozen for the timed region
-    if world > 1 and warm is None:   # --warmup 0: the collection warm-up below still needs one step's results
+    if warm is None:   # --warmup 0: the collection warm-up below still needs one step's results
         warm = warm_step(model, a.w_dtype)
-    if world > 1:
-        # warm the COLLECTION path too: RCCL sets up its point-to-point channels (one per peer) on first use - seconds,
-        # not part of any steady state - so one full-size collection of a warm-up step's results runs before the clock
-        ids = torch.arange(warm[0].shape[0], device=dev, dtype=torch.int64) * world + rank
-        distributed.gather_records_to_root(*distributed.pack_records(ids, warm[0], warm[1]))
-        del ids
+    # warm the COLLECTION path too: RCCL sets up its point-to-point channels (one per peer) on first use - seconds, not part
+    # of any steady state - and with ONE rank the ordering of the records is the first use of a sort / scan / gather kernel
+    # and of their workspace allocations (measured: 7.4 ms behind the last kernel of a 1250-image shard, timeline probe) - so
+    # one full-size collection of a warm-up step's results runs before the clock
+    ids = torch.arange(warm[0].shape[0], device=dev, dtype=torch.int64) * world + rank
+    distributed.gather_records_to_root(*distributed.pack_records(ids, warm[0], warm[1]))
+    del ids
     del warm
     torch.cuda.synchronize()
 

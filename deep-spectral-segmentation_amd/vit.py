@@ -83,7 +83,7 @@ class DinoViT:
     """Inference-only DINO ViT holding its weights on one GPU."""
 
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
-                 dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf",
+                 dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf_f16",
                  linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True,
                  fuse_qkv768: bool = False):
         name = model_name.lower()
