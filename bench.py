@@ -104,8 +104,8 @@ def parse():
     ap.add_argument("--no-fuse-k", action="store_true",
                     help="A/B arm: the hooked block's K projection as LayerNorm + library GEMM + dss_kfeatures_finalize "
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
-    ap.add_argument("--fuse-qkv768", action="store_true",
-                    help="D = 768 models: norm1 -> qkv as one dss_lnlinear_k768 launch instead of LayerNorm + library GEMM (A/B arm)")
+    ap.add_argument("--no-fuse-qkv768", action="store_true",
+                    help="A/B arm (D = 768 models): norm1 -> qkv as LayerNorm + library GEMM instead of one dss_lnlinear_k768 launch")
     ap.add_argument("--gelu", default="erf_f16", choices=["erf", "erf_f16", "tanh_fused"],
                     help="erf_f16 (default, = DinoViT's) = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
                          "operands; error budget: tests/test_host_logic.py::test_gelu_f16_poly_error_budget; bf16 falls back to erf); "
@@ -621,7 +621,7 @@ def main():
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
     model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
-                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=a.fuse_qkv768)
+                    gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     if a.vit_batch <= 0:
@@ -789,7 +789,7 @@ def main():
             # what each layer of THIS model actually ran on (the switches only apply where a kernel exists for the width /
             # patch size: round 4's line claimed fuse_k / fuse_pe for dino_vitb8, where neither path exists)
             "vit_paths": {"switches": {"linear_kres": a.linear_kres, "fuse_ln": not a.no_fuse_ln, "fuse_k": not a.no_fuse_k,
-                                       "fuse_pe": not a.no_fuse_pe, "fuse_qkv768": a.fuse_qkv768}, **model.paths()},
+                                       "fuse_pe": not a.no_fuse_pe, "fuse_qkv768": not a.no_fuse_qkv768}, **model.paths()},
             "library_gemm_ms_per_step_by_site": lib_sites,
             # time until the host had enqueued a step's launches INSIDE the timed loop: it includes the waits of the
             # double-buffered image feeder on the GPU (back-pressure), not only CPU work ...
@@ -810,7 +810,7 @@ def main():
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
         dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
                      fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe,
-                     fuse_qkv768=a.fuse_qkv768)
+                     fuse_qkv768=not a.no_fuse_qkv768)
         for i in range(2):
             warm_step(dl, a.w_dtype)
         torch.cuda.synchronize()

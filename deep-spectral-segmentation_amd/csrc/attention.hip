@@ -49,6 +49,7 @@ __device__ unsigned long long dss_clock_buf[4];
 namespace dss {
 
 static constexpr int DH = 64;  // head dim of every DINO ViT
+static constexpr int ATTN_NW = 8;   // waves per workgroup (32 queries each); 32 KB of LDS per workgroup, <= 128 VGPRs: 16 waves per CU
 typedef __attribute__((address_space(3))) void* lds_as3_t;
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
@@ -182,8 +183,8 @@ __device__ __forceinline__ float exp_rowsum(f32x16& s) {
 // neighbours.  The shader clock inside the workgroups is 1.79-1.87 GHz (1.95-1.97 with LDS, DMA and stores ablated).
 //
 // FLAGS (lab only, results wrong; the library instantiates 0): 4 = no stage barrier, 8 = no DMA inside the loop.
-template <class T, int FLAGS>
-__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+template <class T, int FLAGS, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
                                                           int heads, int nb, int nqb, float scale_log2, int planar) {
   typedef typename vec8<T>::type V8;
   typedef typename vec4<T>::type V4;
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   const long rs = planar ? DH : 3L * heads * DH;                    // row stride (halves)
   const long koff = planar ? heads * plane : (long)heads * DH;      // q -> k ; q -> v is twice that
   const T* base = planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
-  const int q0 = qblk * 256 + wave * 32;
+  static_assert(NW == 8 || NW == 4 || NW == 2, "a stage is eight 1 KB pieces per operand, shared evenly by the waves");
+  const int q0 = qblk * (32 * NW) + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
   DSS_CLOCK_BEGIN
 
@@ -240,15 +242,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   //  32-bit multiply: v_mul_lo_u32 is a quarter-rate instruction in a loop where every VALU slot counts)
   const unsigned dma_max = (unsigned)(Tn - 1) * rb, dma_step = (unsigned)SK * rb;
   unsigned dma_next = (unsigned)(8 * wave + (lane >> 3)) * rb;
-  auto issue = [&](int s) {                                         // wave w moves piece w (8 rows) of K and of V
-    const int r = 8 * wave + (lane >> 3);                           // row inside the stage
-    const unsigned rowoff = dma_next < dma_max ? dma_next : dma_max;   // keys past the end: the last key's row (finite data)
-    dma_next += dma_step;
+  auto issue = [&](int s) {                                         // wave w moves pieces w, w + NW, .. (8 rows each) of K and of V
+    const int r = 8 * wave + (lane >> 3);                           // row of the first piece inside the stage
+    // (rows 8 NW apart share their swizzle: (r >> 1) & 7 and (r >> 1) & 1 repeat every 16 rows)
     const unsigned kc = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
     const unsigned vc = (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s & 1) * 2 * OPB + wave * 1024));
-    dma16(ksrc, rowoff + 16u * kc, dst);
-    dma16(vsrc, rowoff + 16u * vc, dst + OPB);
+#pragma unroll
+    for (int j = 0; j < 8 / NW; ++j) {
+      const unsigned want = dma_next + (unsigned)(8 * NW * j) * rb;
+      const unsigned rowoff = want < dma_max ? want : dma_max;     // keys past the end: the last key's row (finite data)
+      dma16(ksrc, rowoff + 16u * kc, dst + (unsigned)(NW * 1024 * j));
+      dma16(vsrc, rowoff + 16u * vc, dst + OPB + (unsigned)(NW * 1024 * j));
+    }
+    dma_next += dma_step;
   };
   issue(0);
 
@@ -473,8 +480,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 template <class T, int FLAGS = 0>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
                              int planar) {
-  const int nqb = ceil_div(Tn, 256);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, FLAGS>), dim3((unsigned)(nqb * heads * B)), dim3(512), 0, s, (const T*)qkv,
+  const int nqb = ceil_div(Tn, 32 * ATTN_NW);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, FLAGS, ATTN_NW>), dim3((unsigned)(nqb * heads * B)), dim3(64 * ATTN_NW), 0, s, (const T*)qkv,
                      (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
 }
 
@@ -486,7 +493,7 @@ extern "C" int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int
   DSS_REQUIRE(qkv_layout == DSS_ROW_MAJOR || qkv_layout == DSS_PLANAR64,
               "dss_attention_fwd: qkv_layout must be DSS_ROW_MAJOR or DSS_PLANAR64 (got %d)", qkv_layout);
   DSS_REQUIRE(B > 0 && T > 0 && heads > 0, "dss_attention_fwd: bad shape B=%d T=%d heads=%d", B, T, heads);
-  DSS_REQUIRE((long)B * heads * dss::ceil_div(T, 256) < 2147483647L, "dss_attention_fwd: too many workgroups");
+  DSS_REQUIRE((long)B * heads * dss::ceil_div(T, 32 * dss::ATTN_NW) < 2147483647L, "dss_attention_fwd: too many workgroups");
   // the DMA addresses rows with 32-bit byte offsets from the (image, head) base
   DSS_REQUIRE((long)(T + 128) * (qkv_layout == DSS_PLANAR64 ? 128L : 384L * heads) < 4294967296L,   // (+ 128: the carried offset runs one stage ahead)
               "dss_attention_fwd: T=%d x heads=%d exceeds the 32-bit row offsets of the K/V stage DMA", T, heads);

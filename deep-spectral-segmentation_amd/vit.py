@@ -85,7 +85,7 @@ class DinoViT:
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf_f16",
                  linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True,
-                 fuse_qkv768: bool = False):
+                 fuse_qkv768: bool = True):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -121,9 +121,10 @@ class DinoViT:
         # inverse norms is ONE kernel (dss_lnlinear_kfeatures) on the pipeline's path (`extract_k_f16`) instead of
         # LayerNorm + library GEMM + dss_kfeatures_finalize
         self.fuse_k = bool(fuse_k)
-        # fuse_qkv768 (D = 768 models, with fuse_ln): norm1 -> qkv as ONE dss_lnlinear_k768 launch instead of the standalone
+        # fuse_qkv768 (default; D = 768 models, with fuse_ln): norm1 -> qkv as ONE dss_lnlinear_k768 launch instead of the standalone
         # LayerNorm + the library GEMM.  The one-tile K = 768 kernel is slower than hipBLASLt on the GEMM alone (740-771 vs
-        # 888-932 TF/s) but the pair also moves the normalised activations through HBM twice: A/B'd end to end
+        # 888-932 TF/s) but the pair also moves the normalised activations through HBM twice: end to end at C3 the two are equal
+        # within the box noise (822 -> 828 and 840 -> 844 images/s, same box each), and no standalone LayerNorm launch is left
         self.fuse_qkv768 = bool(fuse_qkv768)
         d = self.embed_dim
         sd = state_dict

@@ -88,7 +88,12 @@ int dss_attention_fwd(const void* qkv, int qkv_layout, void* out, int B, int T, 
  * (replaces torch.nn.Linear / nn.GELU inside DINO's Block; reached from extract/extract.py:94).
  * K = 384 (dino_vits16 / dino_vits8): dss_linear_k384, N <= 2048;  K = 768 (dino_vitb16 / dino_vitb8):
  * dss_linear_k768, N <= 3072.  A (row-major), W, bias, C in `dtype` (DSS_F16 / DSS_BF16), fp32 accumulation;
- * N % 64 == 0.  out_layout: DSS_ROW_MAJOR or DSS_PLANAR64 (see above).  K-resident MFMA kernel (linear384.hip). */
+ * N % 64 == 0.  out_layout: DSS_ROW_MAJOR or DSS_PLANAR64 (see above).  K-resident MFMA kernel (linear384.hip).
+ * gelu: 0 = none;  1 = erf-GELU evaluated in fp32 (A&S 7.1.28, |error| <= 3e-7: the output is the correctly rounded `dtype`
+ *       value);  2 (round 5; DSS_F16 only) = the same function as a polynomial form on packed f16 - 5.5 instructions per value
+ *       instead of 17.5, and they co-issue with the other wave's MFMAs: max |error| 1.1e-3 (0.6 of the output's f16 spacing
+ *       where it occurs, at most 2.1 spacings for 0.25 < x < 0.5), <= 3.2e-4 for x < 0, relative <= 2e-3 for |x| < 0.5; its
+ *       arithmetic is restated in tests/util.gelu_f16_poly and pinned bit for bit on the GPU. */
 int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
                     int dtype, void* stream);
 int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
@@ -101,9 +106,11 @@ int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int
  *   C        = act( LayerNorm_eps(x) . W^T + bias ) with LayerNorm's gamma/beta, W and bias given in the folded form that
  *              dss_lnlinear_prepare builds once per layer:  Wg[n][k] = dtype(W[n][k] gamma[k]),
  *              aux[n] = (-sum_k Wg[n][k],  bias[n] + sum_k W[n][k] beta[k])  (f32 [N, 2]).
- * The kernel keeps f16(x) as its K-resident operand (ONE rounding, of x itself) and applies mean / sigma exactly:
- * C = rstd * (x16 . Wg^T - mean * sum_k Wg + sigma * b'), the two corrections as one fp32 MFMA step.  Statistics in fp32
- * from pivot-shifted moments (biased variance, like torch.nn.LayerNorm).  Same shapes / layouts / dtypes as dss_linear_k384
+ * The kernel keeps dtype(x - pivot) as its K-resident operand (ONE rounding; pivot = a robust typical value of the row - the
+ * median of the medians of three column triples -, so the rounding error scales with the row's spread, not with |x|: rows whose
+ * mean is far from zero, up to beyond the f16 range, are as accurate as with a standalone LayerNorm pass; round 5) and applies
+ * mean / sigma exactly: C = rstd * (xp . Wg^T - (mean - pivot) * sum_k Wg + sigma * b'), the two corrections as one fp32 MFMA
+ * step.  Statistics in fp32 from pivot-shifted moments (biased variance, like torch.nn.LayerNorm).  Same shapes / layouts / dtypes as dss_linear_k384
  * / _k768 (K = 384 / 768).  x, residual and C must not alias. */
 int dss_lnlinear_prepare(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg, float* aux,
                          int N, int K, int dtype, void* stream);

@@ -13,7 +13,11 @@ EXTRA=""; [ "$SRC" = attention.hip ] && EXTRA="-fno-honor-nans -mno-amdgpu-ieee"
 PATHSRC=$PKG/csrc/$SRC; REPL=${SRC%.hip}
 if [ "$SRC" = linear384_r4_lab.hip ]; then PATHSRC=scripts/probes/$SRC; REPL=linear384; fi
 if [ "$SRC" = attention_r4_lab.hip ]; then PATHSRC=scripts/probes/$SRC; REPL=attention; EXTRA="-fno-honor-nans -mno-amdgpu-ieee"; fi
+# LAB_SED='s/ATTN_NW = 8/ATTN_NW = 4/': the source is compiled from a sed-edited temporary copy (a constant of the product file changed
+# for ONE A/B build, without a lab macro in the product file)
+if [ -n "${LAB_SED:-}" ]; then sed -e "$LAB_SED" $PATHSRC > scripts/lablib/src_$TAG.hip; PATHSRC=scripts/lablib/src_$TAG.hip; EXTRA="$EXTRA -I $PKG/csrc"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA "$@" -c $PATHSRC -o scripts/lablib/${REPL}_$TAG.o
+rm -f scripts/lablib/src_$TAG.hip
 OBJS=$(ls $PKG/lib/obj/*.o | grep -v "/${REPL}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/lablib/libdss_hip_$TAG.so $OBJS scripts/lablib/${REPL}_$TAG.o
 rm -f scripts/lablib/${REPL}_$TAG.o
