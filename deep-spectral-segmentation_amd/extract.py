@@ -558,14 +558,23 @@ def _iter_images(dataset, todo, processes: int, window: int, device: torch.devic
     at = 0
     # 1.5 MB per image on average (VOC: <= 500 x 500 x 3 = 0.75 MB); what does not fit a block is decoded here
     for entries, block, release in _pump_chunks(pthfast.decode_chunk, chunks, (), processes, per * (3 << 19)):
-        for off, shape in entries:
+        i = 0
+        while i < len(entries):
+            off, shape = entries[i]
             if off is None:                # did not fit the block: decode it here
-                img = dataset[todo[at][0]][0].to(device)
-            else:
-                n = shape[0] * shape[1] * shape[2]
-                img = block[off:off + n].view(shape).to(device, non_blocking=True)
-            yield img, names[at]
-            at += 1
+                yield dataset[todo[at][0]][0].to(device), names[at]
+                at, i = at + 1, i + 1
+                continue
+            # ONE H2D copy per run of same-shape images that lie back to back in the block (a whole chunk on a one-size
+            # dataset) instead of one per image: 20 480 copy calls were ~1 s of the main thread's 8 s at 5 000 images/s
+            n, j = shape[0] * shape[1] * shape[2], i + 1
+            while j < len(entries) and entries[j][1] == shape and entries[j][0] == off + (j - i) * n:
+                j += 1
+            dev = block[off:off + (j - i) * n].view((j - i,) + tuple(shape)).to(device, non_blocking=True)
+            for q in range(j - i):
+                yield dev[q], names[at]
+                at += 1
+            i = j
         release()
 
 
