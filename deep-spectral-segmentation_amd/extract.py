@@ -92,11 +92,18 @@ def _cap_host_threads():
 
 
 def _start_method() -> str:
-    """How the I/O worker processes are started: ``spawn`` (they re-import torch, 1.5-2 s, while the parent keeps
-    working - the job queue is deep enough to absorb that).  ``$DSS_IO_START_METHOD=fork`` was measured on the GPU box:
-    workers are up in milliseconds, but the parent - which holds the HIP context - then runs its own copies 4-5x slower
-    (extract_eigs 352 vs 633 images/s on 2 048 files), so it is not the default."""
-    return os.environ.get("DSS_IO_START_METHOD", "spawn")
+    """How the I/O worker processes are started.  ``forkserver`` (round 5): ONE clean helper process (no HIP context, never
+    imports torch) is spawned, imports what the workers need once (``_FORKSERVER_PRELOAD``) and forks every worker from
+    there in milliseconds - eighty workers are up within the first half second of a run.  Rounds 3-4 used ``spawn``: every
+    worker a fresh interpreter that imports numpy / PIL itself, twelve at a time (48 at once took 3.1 s to deliver a first
+    chunk), so a 20 480-image run spent its first three seconds at a quarter of its decoders.  ``$DSS_IO_START_METHOD=fork``
+    was measured on the GPU box: workers are up in milliseconds too, but the parent - which holds the HIP context - then
+    runs its own copies 4-5x slower (extract_eigs 352 vs 633 images/s on 2 048 files), so it is not an option."""
+    return os.environ.get("DSS_IO_START_METHOD", "forkserver")
+
+
+_FORKSERVER_PRELOAD = ["dss_amd.pthfast", "numpy", "zipfile", "zlib", "pickle", "mmap", "PIL.Image", "PIL.ImageOps",
+                       "PIL.JpegImagePlugin", "PIL.PngImagePlugin"]
 
 
 class _spawn_without_main:
@@ -436,6 +443,8 @@ class _StaggeredPool:
         import torch.multiprocessing as mp
 
         self.ctx = mp.get_context(_start_method())
+        if _start_method() == "forkserver":
+            self.ctx.set_forkserver_preload(_FORKSERVER_PRELOAD)   # (no '__main__': the helper never runs the caller's script)
         self.pools, self.load, self.sizes = [], [], []
         self.lock = threading.Lock()
         self.closing = False
@@ -593,7 +602,7 @@ def _io_processes(n_items: int, most: int = 16, env: str = "") -> int:
         return int(os.environ[env])
     if os.environ.get("DSS_IO_PROCESSES"):
         return int(os.environ["DSS_IO_PROCESSES"])
-    few = 512 if _start_method() == "spawn" else 64   # a spawned interpreter costs ~2 s, a forked one milliseconds
+    few = 512 if _start_method() == "spawn" else 256   # a spawned interpreter costs ~1 s, the fork server ~0.3 s once
     if n_items < few or _shm_free_bytes() < (8 << 30):   # batches travel through /dev/shm: needs room
         return 0
     local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
