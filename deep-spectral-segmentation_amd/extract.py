@@ -426,7 +426,7 @@ def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, bloc
     finally:
         blocks.close()
         if os.environ.get("DSS_CLI_TIMING") and first is not None:
-            print(f"[dss] {fn.__name__}: {processes} workers in waves of {_StaggeredPool.WAVE}, first chunk after {first:.2f} s, "
+            print(f"[dss] {fn.__name__}: {processes} workers ({_start_method()}, waves of {pool.WAVE}), first chunk after {first:.2f} s, "
                   f"all {len(chunks)} chunks after {time.perf_counter() - t_start:.2f} s")
 
 
@@ -436,7 +436,7 @@ class _StaggeredPool:
     twelve are started from a helper thread, and so on.  ``apply_async`` goes to the least loaded pool that is up;
     ``capacity()`` = workers up so far (the producer keeps that many chunks + 2 in flight)."""
 
-    WAVE = 12
+    WAVE = 12          # spawn: interpreters booting at once; the fork server's children cost milliseconds: waves of 32
 
     def __init__(self, processes: int):
         import threading
@@ -448,6 +448,8 @@ class _StaggeredPool:
         self.pools, self.load, self.sizes = [], [], []
         self.lock = threading.Lock()
         self.closing = False
+        if _start_method() != "spawn":
+            self.WAVE = 32
         self._start(min(self.WAVE, processes))
         self.rest = processes - self.sizes[0]
         self.thread = threading.Thread(target=self._grow, daemon=True)
