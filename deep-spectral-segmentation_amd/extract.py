@@ -29,6 +29,7 @@ from __future__ import annotations
 import ast
 import inspect
 import os
+import threading
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from functools import partial
@@ -157,6 +158,14 @@ def _bounded_map(pool: ThreadPoolExecutor, fn, items, window: int):
         yield pending.popleft().result()
 
 
+def _atomic_write(writer, obj, path: str):
+    """``writer(obj, path)`` through a temporary name: a killed run (or an eigen file that is being REWRITTEN because a requested
+    segmentation PNG was missing) never leaves a half-written file for the next run's skip-if-exists to trust."""
+    tmp = f"{path}.tmp{os.getpid()}_{threading.get_ident() & 0xffff:x}"
+    writer(obj, tmp)
+    os.replace(tmp, path)
+
+
 class _AsyncSaver:
     """``torch.save`` off the critical path for SMALL runs: a thread pool (measured: serial saves of 1.4 MB feature files
     cap the CLI at ~120 images/s; threads ~210 - pickling and the zip writer hold the GIL).  Large runs use ``_FastSaver``
@@ -171,7 +180,7 @@ class _AsyncSaver:
         self.max_pending = max_pending
 
     def submit(self, obj, path: str, writer=torch.save):
-        self.futures.append(self.pool.submit(writer, obj, path))
+        self.futures.append(self.pool.submit(_atomic_write, writer, obj, path))
         if len(self.futures) - self.waited >= self.max_pending:  # back-pressure: bound the queued work
             upto = self.waited + self.max_pending // 2
             for f in self.futures[self.waited:upto]:
@@ -307,7 +316,7 @@ def _build_png_file(tensors, item):
 def _write_png(arr, path: str):
     from PIL import Image
 
-    Image.fromarray(arr).save(path)
+    Image.fromarray(arr).save(path, format="PNG")     # (explicit: the name may be a temporary one, see _atomic_write)
 
 
 _SAVE_BUILDERS = {"features": _build_feature_file, "eigs": _build_eig_file, "png": _build_png_file}
@@ -416,6 +425,10 @@ def _pump_chunks(fn, chunks: List[list], extra_args: tuple, processes: int, bloc
                     b = free.popleft() if free else blocks.add()
                     if events[b] is not None:
                         events[b].synchronize()     # the copies out of this block have finished
+                        try:                        # (mmap writes do not refresh a tmpfs file's times: a LIVE run's blocks must
+                            os.utime(blocks.paths[b])   # not look hours-old to another run's _sweep_stale)
+                        except OSError:
+                            pass
                     pending.append((pool.apply_async(fn, (blocks.paths[b], blocks.size, chunks[nxt]) + extra_args), b))
                     nxt += 1
                 res, b = pending.popleft()

@@ -30,7 +30,7 @@ def run(label, timers):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
-    n = sum(len(v) for v in hip.TIMERS.values()) if timers else 0
+    n = sum(len(v) for k_, v in hip.TIMERS.items() if k_ != "_launches") if timers else 0
     hip.TIMERS = None
     print(f"{label}: host enqueue of one {vb}-image forward {min(enq):.2f} ms (median {sorted(enq)[2]:.2f}), "
           f"forward incl. sync {min(tot):.2f} ms; timed launches {n}", flush=True)
