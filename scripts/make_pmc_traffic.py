@@ -17,7 +17,7 @@ def _kres_lnm(name):
     """LNM of a linear_kres_kernel instance (None for other kernels): the template arguments after the element type are
     <GELU, KS, RT, NW, LNM[, PIPE]> - mangled ...linear_kres_kernelIDF16_Lb1ELi24ELi2ELi4ELi<LNM>E[Li0E]EEvPK...; 0 = plain
     Linear, 1 / 2 = LayerNorm prologue."""
-    m = re.search(r"linear_kres_kernelI\w+?_?Lb[01]ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
+    m = re.search(r"linear_kres_kernelI\w+?_?L[bi]\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)   # (GELU: a bool until round 4, an int since)
     if not m:   # demangled: dss::linear_kres_kernel<_Float16, true, 24, 2, 4, 2, 0>
         m = re.search(r"linear_kres_kernel<[^,>]+,\s*\w+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", name)
     return int(m.group(1)) if m else None
