@@ -663,7 +663,10 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
                      dtype: str = "float16", synthetic_weights: Optional[int] = None):
     """Extract features from a list of images (see module docstring).  ``batch_size`` is the maximum
     number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
-    whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76)."""
+    whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76).  ``batch_size <= 0``: as many images as
+    fill FOUR whole rounds of the Linear kernels' workgroups at the first image's size (581 at 480 x 480 / patch 16) - a
+    128-image forward is 0.88 of one round and the GPU side of this command then tops out near 5 000 images/s, a third of
+    what the same kernels do on ~600 images (profiles/r05_cli_throughput.txt)."""
     _make_output_dir_all_ranks(output_dir)
     _cap_host_threads()
     model_name = model_name.lower()
@@ -683,7 +686,7 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
             continue
         todo.append((i, out))
 
-    bs = max(1, int(batch_size))
+    bs = int(batch_size)
     clock = _StageClock()
     with clock("start savers"):   # first of all: the saver processes boot while the model is being built
         n_savers = _io_processes(len(todo), most=32, env="DSS_SAVER_PROCESSES")
@@ -768,11 +771,19 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     # Real datasets (VOC) mix image sizes: bucket by shape so every ViT launch is a full same-shape batch.  At most
     # `max_pending` decoded images wait in the buckets; beyond that the fullest bucket is flushed early.
     buckets: Dict[Tuple[int, ...], List[Tuple[int, Path, torch.Tensor, str]]] = {}
+    auto_bs = bs <= 0
+    bs = max(1, bs) if not auto_bs else 512
     max_pending, n_pending = 8 * bs, 0
     decoded = _iter_images(dataset, todo, decoders, 4 * bs, device)
     for idx, out in todo:
         with clock("wait for decoded image"):
             img, file = next(decoded)
+        if auto_bs:      # sized on the first image: four rounds of 2 x CUs workgroups of the K-resident Linear kernels
+            tokens = (img.shape[0] // patch_size) * (img.shape[1] // patch_size) + 1
+            rows = spectral.hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 256))[1]
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            bs = max(8, int(4 * cus * rows / tokens))
+            max_pending, auto_bs = 8 * bs, False
         bucket = buckets.setdefault(tuple(img.shape), [])
         bucket.append((idx, out, img, file))
         n_pending += 1

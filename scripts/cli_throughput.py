@@ -56,7 +56,9 @@ def main():
     (tmp / "images.txt").write_text("\n".join(f"{i:06d}.jpg" for i in range(n)) + "\n")
     (tmp / "warm.txt").write_text("\n".join(f"{i:06d}.jpg" for i in range(128)) + "\n")
     torch.set_grad_enabled(False)
-    common = dict(images_root=str(tmp / "images"), model_name="dino_vits16", batch_size=128, synthetic_weights=0)
+    bsz = int(os.environ.get("DSS_CLI_BATCH", "128"))     # images per ViT forward (0 = the command's own choice: four rounds of workgroups)
+    print(f"[cli] extract_features batch_size = {bsz}", flush=True)
+    common = dict(images_root=str(tmp / "images"), model_name="dino_vits16", batch_size=bsz, synthetic_weights=0)
     extract.extract_features(images_list=str(tmp / "warm.txt"), output_dir=str(tmp / "warm_feat"), **common)  # warm-up
     mon = Monitor(tmp / "feat", n)
     t0 = time.time()
