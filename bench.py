@@ -54,10 +54,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0,
                     help="images per step per GPU (0 = 4..8 ViT forwards, whichever fills whole rounds of eigensolver "
-                         "workgroups best: 4 x 1018 = 4072 at the headline config)")
+                         "workgroups best: 4 x 2036 = 8144 at the headline config)")
     ap.add_argument("--vit-batch", type=int, default=0,
-                    help="images per ViT forward (0 = ~1 M token rows, sized so the token matrix fills whole waves of "
-                         "workgroups: vit.wave_filling_batch; 1018 for dino_vits16 at 480x480)")
+                    help="images per ViT forward (0 = ~1.8 M token rows, sized so the token matrix fills whole waves of "
+                         "workgroups: vit.wave_filling_batch; 2036 for dino_vits16 at 480x480)")
     ap.add_argument("--dataset", type=int, default=0,
                     help="strong scaling: a fixed set of this many images sharded round-robin over the ranks "
                          "(BASELINE.json configs[3]: 10000); --steps is then derived from the shard")
@@ -470,6 +470,21 @@ def pmc_traffic(kernel, a):
     return best
 
 
+def cpu_quota_cores():
+    """CPUs the container may actually use at once (cgroup v2 `cpu.max` / v1 `cpu.cfs_quota_us`), or None if unlimited: the
+    GPU boxes show 256 cores to `nproc` under a quota of 16 - what `cores` (the threads the oracle ran) could really draw on."""
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        pass
+    try:
+        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        return None if q <= 0 else round(q / int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text()), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol, n_parity=0):
     """The oracle (CPU restatement of the reference path) on the same synthetic images/weights, all host
     cores; also yields the eigenvector parity of the GPU results on those images: the rule of tests/util.check_eigs
@@ -508,7 +523,8 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol,
                           # how far the chained cluster reaches in eigenvalue (a tight pair vs a long chain of 1e-4 gaps)
                           "cluster_span": float(f"{float(lam_x[min(c['last'], len(lam_x) - 1)] - lam_x[c['first']]):.3g}")}
                          for c in report if c["kind"] != "isolated"])
-    return ({"value": round(len(times) / sum(times), 3), "unit": "images/s", "cores": cores, "kind": "port",
+    return ({"value": round(len(times) / sum(times), 3), "unit": "images/s", "cores": cores, "cpu_quota_cores": cpu_quota_cores(),
+             "kind": "port",
              "sample": f"{len(times)} of the same {size}x{size} synthetic images, torch-CPU fp32 ViT + "
                        f"numpy/scipy eigsh (oracle/), 1 warm-up image excluded"},
             {"rule": "tests/util.check_eigs: every cluster of eigenvalues (gaps < 1e-4) bounded by 1e-4; isolated -> "
@@ -639,8 +655,13 @@ def main():
         # ~0.9 M token rows per forward (1018 images at the headline config): measured round 4 on one box, images/s with
         # 290 / 435 / 580 / 1160 images per forward = 12 213 / 12 430 / 12 635 / 12 754 - per-launch tails and the ~7 us between
         # launches are paid per forward, HBM (288 GB) is nowhere near a limit (a forward's activations: < 15 GB)
-        target = max(8, round(1024 * 901 / (n_patches + 1)))
+        # Round 5: ~1.8 M rows (2036 images: 14 rounds of workgroups) - 1018 -> 2036 images per forward measured +1.5 % on one box
+        # (13 946 / 13 921 -> 14 149 images/s); bounded by the 32-bit row arithmetic of the hand-over kernel (M * D * 4 < 2^32)
+        row_cap = int(0.9 * 2 ** 32 / (4 * model.embed_dim))
+        target = max(8, round(min(2048 * 901, row_cap) / (n_patches + 1)))
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
+        while a.vit_batch * (n_patches + 1) > row_cap:      # (wave_filling_batch may round up to 25 % above the target)
+            a.vit_batch -= 1
     global ROUND_IMAGES
     rows_cu = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
     ROUND_IMAGES = ncu * rows_cu / (n_patches + 1) if rows_cu and a.linear_kres and not a.balanced_chunks else 0.0   # see chunk_counts
