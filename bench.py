@@ -494,6 +494,18 @@ def cpu_baseline(model_name, sd, size, K, n_images, gpu_vecs, gpu_vals, lam_tol,
     from tests.util import build_w64, check_eigs
 
     ref = vit_ref.build_ref_vit(model_name, sd)
+    # the reference's CPU path on the cores this container can really use: under a cgroup quota (16 CPUs on the GPU boxes, where
+    # torch defaults to 128 threads and numpy's BLAS to 256) more threads than CPUs only add contention - torch's intra-op pool
+    # and the BLAS / OpenMP pools behind numpy and scipy are capped at the quota
+    quota = cpu_quota_cores()
+    limiter = None
+    if quota:
+        torch.set_num_threads(max(1, math.ceil(quota)))
+        try:
+            from threadpoolctl import threadpool_limits
+            limiter = threadpool_limits(limits=max(1, math.ceil(quota)))
+        except Exception:
+            limiter = None
     cores = torch.get_num_threads()
     times, worst_vec, worst_cluster, ok, clusters, draws = [], 0.0, 0.0, True, [], []
     n_total = max(n_images + 1, n_parity)
