@@ -669,7 +669,7 @@ def main():
         # launches are paid per forward, HBM (288 GB) is nowhere near a limit (a forward's activations: < 15 GB)
         # Round 5: ~1.8 M rows (2036 images: 14 rounds of workgroups) - 1018 -> 2036 images per forward measured +1.5 % on one box
         # (13 946 / 13 921 -> 14 149 images/s); bounded by the 32-bit row arithmetic of the hand-over kernel (M * D * 4 < 2^32)
-        row_cap = int(0.9 * 2 ** 32 / (4 * model.embed_dim))
+        row_cap = int(0.9 * 2 ** 32 / max(4 * model.embed_dim, n_patches + 1))   # (... and M * T < 2^32: its row -> image division)
         target = max(8, round(min(2048 * 901, row_cap) / (n_patches + 1)))
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
         while a.vit_batch * (n_patches + 1) > row_cap:      # (wave_filling_batch may round up to 25 % above the target)
