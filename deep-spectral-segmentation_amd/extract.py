@@ -1076,6 +1076,13 @@ def _segmentation_job(pair, output_dir: str):
     return target, (int(sizes[5]), int(sizes[6])), meta, torch.load(eigs_path, map_location="cpu", weights_only=False)
 
 
+def _consumer_device() -> torch.device:
+    """Where the segmentation commands compute: the GPU when there is one (the kernels of `csrc/segment.hip`), the host
+    otherwise - the reference ran them on the CPU, and `spectral.single_region_masks` / `multi_region_segments` / `kmeans_lloyd`
+    are plain tensor code for host tensors (the two hot commands have no such fallback)."""
+    return local_device() if torch.cuda.is_available() else torch.device("cpu")
+
+
 def _save_label_png(labels: torch.Tensor, target: Path) -> None:
     from PIL import Image
 
@@ -1089,7 +1096,7 @@ def _extract_single_region_segmentations(inp: Tuple[int, Tuple[str, str]], thres
     if job is None:
         return
     target, (rows, cols), _, eig = job
-    vec = eig["eigenvectors"].to(local_device(), torch.float32)[None]
+    vec = eig["eigenvectors"].to(_consumer_device(), torch.float32)[None]
     _save_label_png(spectral.single_region_masks(vec, threshold)[0].view(rows, cols), target)
 
 
@@ -1114,7 +1121,7 @@ def _extract_multi_region_segmentations(inp: Tuple[int, Tuple[str, str]], adapti
     if job is None:
         return
     target, (rows, cols), meta, eig = job
-    dev = local_device()
+    dev = _consumer_device()
     lam = eig["eigenvalues"].to(dev, torch.float32)[None]
     vec = eig["eigenvectors"].to(dev, torch.float32)[None]
     points = vec.shape[-1]
@@ -1127,7 +1134,7 @@ def _extract_multi_region_segmentations(inp: Tuple[int, Tuple[str, str]], adapti
         if feats.shape[0] != points:
             raise ValueError(f"{meta['id']}: kmeans_baseline needs one feature row per eigenvector entry")
         k = spectral.adaptive_num_segments(lam)[0] if adaptive else int(non_adaptive_num_segments)
-        labels = spectral.kmeans_lloyd(feats, k, seed=seed).view(grid)
+        labels = spectral.kmeans_lloyd(feats, k, seed=seed, n_init=1 if feats.is_cuda else 4).view(grid)
         if infer_bg_index:
             labels = spectral.border_owner_to_zero(labels)
     else:

@@ -289,7 +289,10 @@ def eigs_from_dense_affinity(w: torch.Tensor, K: int, problem: str = "laplacian"
 @torch.no_grad()
 def single_region_masks(eigenvectors: torch.Tensor, threshold: float = 0.0) -> torch.Tensor:
     """extract.py:383-407 on the device, straight from the solver's output: u8 ``[B, N]`` masks (0 / 255) of
-    ``eigenvectors[:, 1] > threshold`` - reshape ``(H_patch, W_patch)`` for the PNG the reference writes."""
+    ``eigenvectors[:, 1] > threshold`` - reshape ``(H_patch, W_patch)`` for the PNG the reference writes.  Host tensors (a
+    machine without a GPU running the segmentation commands, as the reference did) take the same comparison in torch."""
+    if not eigenvectors.is_cuda:
+        return (eigenvectors[:, 1] > threshold).to(torch.uint8) * 255
     return hip.fiedler_mask(eigenvectors, 1, threshold)
 
 
@@ -314,11 +317,23 @@ def border_owner_to_zero(labels: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def kmeans_lloyd(points: torch.Tensor, k: int, seed: int = 0, max_iter: int = 300, tol: float = 1e-4) -> torch.Tensor:
+def kmeans_lloyd(points: torch.Tensor, k: int, seed: int = 0, max_iter: int = 300, tol: float = 1e-4, n_init: int = 1) -> torch.Tensor:
     """Plain Lloyd K-means on the device for what ``dss_kmeans_segments`` does not take (more than 8192 points / 64
     coordinates / 32 clusters; the reference's ``kmeans_baseline`` over raw 384-d features): k-means++ seeding from a
     seeded generator, iterations until the labels repeat or the squared centre shift is below ``tol`` x the mean
-    coordinate variance (sklearn's two rules).  ``points [N, d]`` f32 -> ``[N]`` int64 labels."""
+    coordinate variance (sklearn's two rules).  ``points [N, d]`` f32 -> ``[N]`` int64 labels.  ``n_init > 1``: that many runs
+    from seeds ``seed, seed + 1, ..``, the tightest partition wins (what sklearn's ``n_init`` does; the host fallback of the
+    segmentation commands uses 4)."""
+    if n_init > 1:
+        best, best_inertia = None, float("inf")
+        for r in range(int(n_init)):
+            lab = kmeans_lloyd(points, k, seed + r, max_iter, tol)
+            cen = torch.zeros((int(lab.max()) + 1, points.shape[1]), dtype=points.dtype, device=points.device).index_add_(0, lab, points)
+            cen = cen / torch.bincount(lab, minlength=cen.shape[0]).clamp(min=1).unsqueeze(1)
+            inertia = float((points - cen[lab]).square().sum())
+            if inertia < best_inertia:
+                best, best_inertia = lab, inertia
+        return best
     n, _ = points.shape
     k = max(1, min(int(k), n))
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
@@ -364,13 +379,14 @@ def multi_region_segments(eigenvalues: torch.Tensor, eigenvectors: torch.Tensor,
     for kk in sorted(set(ks)):
         idx = [i for i, v in enumerate(ks) if v == kk]
         sel = torch.tensor(idx, device=eigenvectors.device)
-        if n <= 8192 and 1 <= dims <= 64 and 1 <= kk <= 32:
+        if eigenvectors.is_cuda and n <= 8192 and 1 <= dims <= 64 and 1 <= kk <= 32:   # (host tensors: the tensor route below)
             lab, _, _ = hip.kmeans_segments(eigenvectors[sel].contiguous(), kk, first=1, dims=dims, grid=grid,
                                             infer_bg=infer_bg_index, init=None if init is None else init[sel], seed=seed)
             out[sel] = lab
         else:
             for i in idx:
-                lab = kmeans_lloyd(eigenvectors[i, 1:1 + dims].t().contiguous(), kk, seed=seed).view(grid)
+                lab = kmeans_lloyd(eigenvectors[i, 1:1 + dims].t().contiguous(), kk, seed=seed,
+                                   n_init=1 if eigenvectors.is_cuda else 4).view(grid)
                 out[i] = (border_owner_to_zero(lab) if infer_bg_index else lab).reshape(-1).to(torch.uint8)
     return out.view(b, grid[0], grid[1])
 

@@ -97,6 +97,47 @@ def test_single_region_command_matches_reference_png(tmp_path):
     assert png.dtype == np.uint8 and np.array_equal(png, g["png"])
 
 
+def test_segmentation_commands_fall_back_to_the_host_without_a_gpu(tmp_path, monkeypatch):
+    """The reference ran `extract_single_region_segmentations` / `extract_multi_region_segmentations` on the CPU; here they use
+    the device kernels when a GPU is there and plain tensor code otherwise (`extract._consumer_device`).  Forced onto the host:
+    the single-region PNG is the reference's bit for bit (tests/golden/single_region.npz), the multi-region command gives the
+    reference's grid and number of segments, a partition at least as tight as the reference's draw to 15 %, the border rule,
+    and a deterministic second run."""
+    from PIL import Image
+
+    monkeypatch.setattr(extract, "_consumer_device", lambda: torch.device("cpu"))
+    g = np.load(GOLDEN / "single_region.npz")
+    (tmp_path / "f").mkdir(), (tmp_path / "e").mkdir()
+    n = g["eigenvectors"].shape[1]
+    torch.save({"k": torch.zeros(1, n, 8), "indices": torch.tensor(0), "file": "img.jpg", "id": "img", "model_name": "dino_vits16",
+                "patch_size": int(g["patch"]), "shape": tuple(int(v) for v in g["shape"])}, tmp_path / "f" / "img.pth")
+    torch.save({"eigenvalues": torch.zeros(g["eigenvectors"].shape[0]), "eigenvectors": torch.from_numpy(g["eigenvectors"])},
+               tmp_path / "e" / "img.pth")
+    extract.extract_single_region_segmentations(str(tmp_path / "f"), str(tmp_path / "e"), str(tmp_path / "o"))
+    png = np.array(Image.open(tmp_path / "o" / "img.png"))
+    assert png.dtype == np.uint8 and np.array_equal(png, g["png"])
+    g = np.load(GOLDEN / "consumers.npz")
+    for case in (0, 2):
+        sub = tmp_path / f"c{case}"
+        sub.mkdir()
+        name, kind, hw, factor, K, seed, kw = _cases(g)[case]
+        _write_case(sub, g, name, kind, hw, factor, K)
+        extract.extract_multi_region_segmentations(features_dir=str(sub / "f"), eigs_dir=str(sub / "e"), output_dir=str(sub / "o"), **kw)
+        png, want = np.array(Image.open(sub / "o" / f"{name}.png")), g[f"{name}__png"]
+        assert png.dtype == np.uint8 and png.shape == want.shape and len(np.unique(png)) == len(np.unique(want))
+        vec = g[f"{name}__eigenvectors"]
+        if kw.get("kmeans_baseline"):
+            pts = synthetic.synthetic_features(kind, hw[0] * hw[1], 384, 500 + len(name), tuple(hw)).astype(np.float64)
+        else:
+            pts = vec[1:1 + min(kw.get("num_eigenvectors", 1_000_000), vec.shape[0] - 1)].T.astype(np.float64)
+        assert _inertia(pts, png.reshape(-1)) <= 1.15 * _inertia(pts, want.reshape(-1)) + 1e-9
+        if kw.get("infer_bg_index", True):
+            idx, frac = extract_utils.get_border_fraction(png)
+            assert idx[np.argmax(frac)] == 0
+        extract.extract_multi_region_segmentations(features_dir=str(sub / "f"), eigs_dir=str(sub / "e"), output_dir=str(sub / "o2"), **kw)
+        assert np.array_equal(np.array(Image.open(sub / "o2" / f"{name}.png")), png)
+
+
 def test_kmeans_lloyd_and_border_rule_on_the_host():
     """spectral.kmeans_lloyd / border_owner_to_zero / adaptive_num_segments are plain tensor code (the route for problems
     beyond the K-means kernel's limits): separated blobs are recovered exactly, the run is deterministic in its seed, the
