@@ -170,9 +170,10 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
   // epilogue: relu; rows/columns >= N are written as 0 (the matvec relies on it); each half-wave stores 32
   // consecutive floats (128 B) of a tile row.  The whole 64x64 storage tile is always written.
   if (!quad) return;
-  WE* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  const WsymLayout LW = wsym_layout(N);             // where tile (ti, tj) lives: a full tile, or mini tiles of the edge strip
   auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
     const int col = cj0 + csub + li;
+    if (!wsym_has(LW, tj, csub + li)) return;        // a column of the edge the strip does not keep (>= N: zero anyway)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lr = rsub + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -180,11 +181,12 @@ __global__ __launch_bounds__(256) void gram_relu_kernel(const float* __restrict_
       float v = computed ? acc[r] : 0.f;
       if (relu) v = fmaxf(v, 0.f);
       if (row >= N || col >= N) v = 0.f;
+      WE* dst = Wb + wsym_at(LW, ti, tj, lr, csub + li);
       if constexpr (sizeof(WE) == 4) {
-        tile[lr * 64 + csub + li] = v;
+        *dst = v;
       } else {
         const float q = __builtin_rintf(fminf(fmaxf(v, 0.f), 1.0f) * 65535.0f);
-        tile[lr * 64 + csub + li] = (WE)(unsigned)q;
+        *dst = (WE)(unsigned)q;
       }
     }
   };
@@ -320,9 +322,10 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
   }
 
   if (!quad) return;
-  WE* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  const WsymLayout LW = wsym_layout(N);             // where tile (ti, tj) lives: a full tile, or mini tiles of the edge strip
   auto store_tile = [&](const f32x16& acc, int rsub, int csub, bool computed) {
     const int col = cj0 + csub + li;
+    if (!wsym_has(LW, tj, csub + li)) return;        // a column of the edge the strip does not keep (>= N: zero anyway)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lr = rsub + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -330,11 +333,12 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const f16* __restrict__
       float v = computed ? acc[r] : 0.f;
       if (relu) v = fmaxf(v, 0.f);
       if (row >= N || col >= N) v = 0.f;
+      WE* dst = Wb + wsym_at(LW, ti, tj, lr, csub + li);
       if constexpr (sizeof(WE) == 4) {
-        tile[lr * 64 + csub + li] = v;
+        *dst = v;
       } else {
         const float q = __builtin_rintf(fminf(fmaxf(v, 0.f), 1.0f) * 65535.0f);
-        tile[lr * 64 + csub + li] = (WE)(unsigned)q;
+        *dst = (WE)(unsigned)q;
       }
     }
   };
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __r
   if (!quad) return;
   // epilogue: w = <x_i, x_j> / (|x_i| |x_j|); round(65535 clamp(w, 0, 1)) is ONE v_cvt_pknorm_u16_f32 per pair (the clamp
   // is the relu); rows / columns >= N are written as 0 (the matvec relies on it).  The whole storage tile is written.
-  uint16_t* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  const WsymLayout LW = wsym_layout(N);             // where tile (ti, tj) lives: a full tile, or mini tiles of the edge strip
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   auto store_tile = [&](const f32x16& acc, int rsub, int csub) {
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256, 3) void gram_f16_fused_kernel(const float* __r
       for (int i = 0; i < 4; ++i) w[i] = cj0 + lc + i < N ? acc[4 * g + i] * rr * rc[i] : 0.f;
       const u16x2 q0 = __builtin_amdgcn_cvt_pknorm_u16(w[0], w[1]), q1 = __builtin_amdgcn_cvt_pknorm_u16(w[2], w[3]);
       const u32x2 out = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-      *reinterpret_cast<u32x2*>(tile + lrow * 64 + lc) = out;
+      if (wsym_has(LW, tj, lc)) *reinterpret_cast<u32x2*>(Wb + wsym_at(LW, ti, tj, lrow, lc)) = out;   // (4 columns: one mini-tile row)
     }
   };
   store_tile(acc00, 0, 0);
@@ -673,7 +677,9 @@ __global__ __launch_bounds__(512, 4) void gram_f16_dma_kernel(const f16* __restr
   if (!compute) return;
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  uint16_t* tile = Wb + (size_t)(wsym_row_start(ti, nt) + (tj - ti)) * 64 * 64;
+  const WsymLayout LW = wsym_layout(N);             // where tile (ti, tj) lives: a full tile, or mini tiles of the edge strip
+  const bool edge = tj >= LW.ntf;                   // wave-uniform
+  uint16_t* tile = Wb + wsym_at(LW, ti, tj, 0, 0);
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int lrow = 32 * a + li;                         // this lane's row inside the tile
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(512, 4) void gram_f16_dma_kernel(const f16* __restr
         const u16x2 q0 = __builtin_amdgcn_cvt_pknorm_u16(A[4 * g] * rr * rc[0], A[4 * g + 1] * rr * rc[1]);
         const u16x2 q1 = __builtin_amdgcn_cvt_pknorm_u16(A[4 * g + 2] * rr * rc[2], A[4 * g + 3] * rr * rc[3]);
         const u32x2 out = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-        *reinterpret_cast<u32x2*>(tile + lrow * 64 + lc) = out;
+        if (!edge) *reinterpret_cast<u32x2*>(tile + lrow * 64 + lc) = out;
+        else if (lc < 4 * LW.e4) *reinterpret_cast<u32x2*>(tile + ((lc >> 2) * 64 + lrow) * 4) = out;   // mini tile lc / 4, row lrow
       }
     }
   }
@@ -741,7 +748,7 @@ extern "C" int dss_normalize_rows(const float* x, float* y, int rows, int D, flo
 }
 
 extern "C" int dss_affinity_ld(int N) { return N > 0 ? dss::round_up(N, 64) : 0; }
-extern "C" size_t dss_affinity_elems(int N) { return N > 0 ? dss::wsym_floats(dss_affinity_ld(N)) : 0; }
+extern "C" size_t dss_affinity_elems(int N) { return N > 0 ? dss::wsym_elems(N) : 0; }
 
 extern "C" int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,
                             void* stream) {

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(EIGS_THREADS, EIGS_WAVES_PER_SIMD) void laplacian_e
                                                                       int32_t* info) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const size_t b = blockIdx.x;
-  eigs_one_image(W + b * wsym_floats(P.ld), P, gws + b * gws_stride, lds, eigenvalues + b * P.K,
+  eigs_one_image(W + b * wsym_elems(P.N), P, gws + b * gws_stride, lds, eigenvalues + b * P.K,
                  eigenvectors + b * (size_t)P.K * P.N, info + b);
 }
 

@@ -27,6 +27,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #ifdef DSS_HOST_EMUL
 #define DSS_DEV
@@ -45,6 +46,7 @@
 #define DSS_RSQRT64(x) (1.0 / sqrt(x))
 #define DSS_SETPRIO(p) ((void)0)
 #define DSS_UNIFORM(p) ((void)0)
+#define DSS_UNIFORM_INT(x) ((void)0)
 #define DSS_F64C(x) ((double)(float)(x))
 #define DSS_FRESH_F32(x) (x)
 #else
@@ -79,6 +81,7 @@ template <class T> __device__ __forceinline__ T* dss_uniform_ptr(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 #define DSS_UNIFORM(p) ((p) = dss_uniform_ptr(p))
+#define DSS_UNIFORM_INT(x) ((x) = __builtin_amdgcn_readfirstlane(x))   /* a workgroup-uniform int read from LDS: keep it scalar */
 // An fp64 literal that is not an inline constant occupies a register PAIR, which hipcc hoists out of every loop and keeps
 // for the whole kernel (and then spills).  Thresholds and 1.5 are exact enough as an f32 literal widened where it is used.
 __device__ __forceinline__ double dss_f64c(float c) { asm volatile("" : "+v"(c)); return (double)c; }
@@ -164,13 +167,39 @@ DSS_HD inline EigsLds eigs_lds_layout(int ld, int ncv) {
   return L;
 }
 // ---- packed symmetric storage of W -------------------------------------------------------------------------
-// W is symmetric, so only its upper-triangular 64x64 tiles are stored and streamed: with nt = ld/64 tile rows,
-// tile (I, J), J >= I, is the t-th 4096-float block, t = I*nt - I*(I-1)/2 + (J - I), row-major inside the tile.
-// Diagonal tiles are stored in full.  Rows/columns >= N hold zeros.  N = 900: 120 tiles (1.97 MB) instead of 3.46 MB.
+// W is symmetric, so only its upper-triangular 64x64 tiles are stored and streamed, as BLOCKS of 4096 elements:
+//   * full tiles: tile (I, J), I <= J < ntf, is block t = I*ntf - I*(I-1)/2 + (J - I), row-major inside the tile; diagonal
+//     tiles are stored in full;
+//   * the EDGE STRIP (round 5): when the last tile column holds only r = N mod 64 <= 16 columns of the matrix (N = 900: 4,
+//     N = 3600 / 784 / 400: 16) it is not stored as 64-wide tiles but as MINI TILES of 64 rows x 4 columns, [row][4], mini tile
+//     m = I * e4 + e holding columns 4e .. 4e+3 of the edge for tile row I = 0 .. ntf (I = ntf is the r x r corner, stored in
+//     full); 4 e4 = 4 (r <= 4) or 16 columns are kept.  16 mini tiles are one block; they follow the full tiles, the last
+//     block padded (its unused mini tiles are never read).  N = 900: 105 + 1 blocks = 1.07x the N (N + 1) / 2 elements of the
+//     triangle, where 15 x 16 / 2 = 120 tiles were 1.21x (3.46 MB -> 1.97 MB -> 1.74 MB as float).
+// Rows / columns >= N hold zeros.  ld = 64 nt stays the length of every vector of the solver.
 static constexpr int WT = 64;
-DSS_HD inline int wsym_tiles(int nt) { return nt * (nt + 1) / 2; }
-DSS_HD inline size_t wsym_floats(int ld) { return (size_t)wsym_tiles(ld / WT) * WT * WT; }
-DSS_HD inline int wsym_row_start(int I, int nt) { return I * nt - I * (I - 1) / 2; }
+struct WsymLayout {
+  int nt;    // tile rows / columns of the matrix: ceil(N / 64)
+  int ntf;   // ... of them stored as full tiles: nt, or nt - 1 in front of an edge strip
+  int e4;    // edge strip: 4 e4 columns of tile column ntf are kept (0: no strip)
+};
+DSS_HD inline WsymLayout wsym_layout(int N) {
+  const int nt = (N + WT - 1) / WT, r = N - (N / WT) * WT;
+  WsymLayout L = {nt, nt, 0};
+  if (nt > 1 && r >= 1 && r <= 16) { L.ntf = nt - 1; L.e4 = r <= 4 ? 1 : 4; }
+  return L;
+}
+DSS_HD inline int wsym_row_start(int I, int ntf) { return I * ntf - I * (I - 1) / 2; }
+DSS_HD inline int wsym_full_tiles(const WsymLayout& L) { return L.ntf * (L.ntf + 1) / 2; }
+DSS_HD inline int wsym_minis(const WsymLayout& L) { return L.e4 ? (L.ntf + 1) * L.e4 : 0; }
+DSS_HD inline int wsym_blocks(const WsymLayout& L) { return wsym_full_tiles(L) + (wsym_minis(L) + 15) / 16; }
+DSS_HD inline size_t wsym_elems(int N) { return (size_t)wsym_blocks(wsym_layout(N)) * WT * WT; }
+// is column lc of tile column tj stored at all / where element (lr, lc) of tile (ti, tj), ti <= tj, lives
+DSS_HD inline bool wsym_has(const WsymLayout& L, int tj, int lc) { return tj < L.ntf || lc < 4 * L.e4; }
+DSS_HD inline size_t wsym_at(const WsymLayout& L, int ti, int tj, int lr, int lc) {
+  if (tj < L.ntf) return ((size_t)(wsym_row_start(ti, L.ntf) + (tj - ti)) * WT + lr) * WT + lc;
+  return (size_t)wsym_full_tiles(L) * WT * WT + ((size_t)(ti * L.e4 + (lc >> 2)) * WT + lr) * 4 + (lc & 3);
+}
 
 // global workspace per image (floats): two basis buffers [(ncv+1) x ld] + dis[ld]
 DSS_HD inline size_t eigs_ws_floats_per_image(int ld, int ncv) { return (size_t)2 * (ncv + 1) * ld + ld; }
@@ -335,6 +364,48 @@ DSS_DEV void matvec_finish_tile(float (&rp)[16], float c0_, float c1_, float c2_
 }
 #endif
 
+#ifndef DSS_HOST_EMUL
+// One MINI TILE of the edge strip (64 rows x 4 columns; `raw` = this lane's row: 4 x u16 in two words, or 4 floats): tile row
+// I = m / e4, edge columns 4 e .. 4 e + 3 with e = m % e4.  A lane owns one ROW: its 4 products with x_edge go to y_I[lane];
+// its 4 column partials a[c] x_I[lane] are summed over the lanes by a halving butterfly (7 exchanges; column lane >> 4 ends
+// in the lane) and go to y_edge.  The corner (I = ntf) is stored in full and contributes rows only.
+template <class RAW>
+DSS_DEV void matvec_strip_mini(const RAW& raw, int m, int e4, int ntf, const float* xs, float* ws, int lane) {
+  const int I = e4 == 1 ? m : m >> 2, e = m & (e4 - 1);   // e4 is 1 or 4 (wsym_layout)
+  const float xi = I < ntf ? xs[I * WT + lane] : 0.f;
+  const f32x4 xj = *reinterpret_cast<const f32x4*>(xs + ntf * WT + 4 * e);
+  float a0, a1, a2, a3;
+  if constexpr (sizeof(RAW) == 8) {
+    a0 = (float)(raw[0] & 0xffffu); a1 = (float)(raw[0] >> 16);
+    a2 = (float)(raw[1] & 0xffffu); a3 = (float)(raw[1] >> 16);
+  } else {
+    a0 = raw[0]; a1 = raw[1]; a2 = raw[2]; a3 = raw[3];
+  }
+  atomicAdd(&ws[I * WT + lane], (a0 * xj[0] + a1 * xj[1]) + (a2 * xj[2] + a3 * xj[3]));
+  if (I < ntf) {                                           // (wave-uniform)
+    float c0 = a0 * xi, c1 = a1 * xi, c2 = a2 * xi, c3 = a3 * xi;
+    {
+      const bool up = (lane & 32) != 0;
+      const float s0 = up ? c0 : c2, s1 = up ? c1 : c3;
+      const float k0 = up ? c2 : c0, k1 = up ? c3 : c1;
+      c0 = k0 + lane_xor<32>(s0, lane);
+      c1 = k1 + lane_xor<32>(s1, lane);
+    }
+    {
+      const bool up = (lane & 16) != 0;
+      const float send = up ? c0 : c1;
+      const float keep = up ? c1 : c0;
+      c0 = keep + lane_xor<16>(send, lane);
+    }
+    c0 += lane_xor<8>(c0, lane);
+    c0 += lane_xor<4>(c0, lane);
+    c0 += lane_xor<2>(c0, lane);
+    c0 += lane_xor<1>(c0, lane);
+    if ((lane & 15) == 0) atomicAdd(&ws[ntf * WT + 4 * e + (lane >> 4)], c0);   // column 2 (bit 5) + (bit 4) = lane >> 4
+  }
+}
+#endif
+
 #ifdef DSS_EIGS_PLAIN_LOADS   // lab: W through the default cache policy instead of the streaming (nt) one
 #define DSS_W_LOAD(p) (*(p))
 #else
@@ -347,11 +418,22 @@ struct NoSideJob { DSS_DEV void operator()() const {} };
 template <class WE, class Side = NoSideJob>
 DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* xs, float* ws, const float* dis,
                         bool scale, bool side_on = false, const Side& side = Side()) {
-  const int nt = ld / WT;
+  const WsymLayout LW = wsym_layout(N);            // ld == 64 LW.nt
+  const int nt = LW.ntf;                           // tile rows / columns stored as full tiles
   for (int e = DSS_TID; e < ld; e += DSS_NT) ws[e] = 0.f;
   DSS_SYNC();
 #ifdef DSS_HOST_EMUL
   if (side_on) side();
+  for (int m = 0; m < wsym_minis(LW); ++m) {       // the edge strip: mini tile m = 64 rows x 4 columns (see wsym_layout)
+    const int I = m / LW.e4, e = m % LW.e4;
+    const WE* A = Wp + (size_t)wsym_full_tiles(LW) * WT * WT + (size_t)m * WT * 4;
+    for (int r = 0; r < WT; ++r)
+      for (int c = 0; c < 4; ++c) {
+        const float a = (float)A[r * 4 + c];
+        ws[I * WT + r] += a * xs[nt * WT + 4 * e + c];
+        if (I < nt) ws[nt * WT + 4 * e + c] += a * xs[I * WT + r];   // (the corner I == nt is stored in full)
+      }
+  }
   for (int I = 0; I < nt; ++I)
     for (int J = I; J < nt; ++J) {
       const WE* A = Wp + (size_t)(wsym_row_start(I, nt) + (J - I)) * WT * WT;
@@ -370,7 +452,7 @@ DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* x
 #else
   const int lane = DSS_LANE;
   const int g = lane >> 4, q = lane & 15;         // lane -> rows 4k + g (k = 0..15), columns 4q .. 4q+3
-  const int ntiles = wsym_tiles(nt);
+  const int ntiles = wsym_full_tiles(LW), nmini = wsym_minis(LW);
   int I = 0, row_start = 0;                        // tile row of the current tile index (advanced incrementally)
   const bool split = side_on && DSS_NWAVES > 1;
   const int stream_waves = split ? DSS_NWAVES - 1 : DSS_NWAVES;
@@ -527,6 +609,30 @@ DSS_DEV void matvec_sym(const WE* __restrict__ Wp, int N, int ld, const float* x
       }
       // owned column: 4*q + 2*(g & 1) + (g >> 1)
       atomicAdd(&ws[J * WT + 4 * q + 2 * (g & 1) + (g >> 1)], c0);
+    }
+  }
+  // The edge strip, behind the tiles: its mini tiles (512 B of 16-bit W each) go round-robin to the streaming waves from the
+  // LAST one down - tile t went to wave t mod stream_waves, so those are the waves with one tile less (N = 900: 105 tiles over
+  // 8 waves = 14 for wave 0, 13 for the others, and the 15 mini tiles are 2-3 per wave of a fifth of a tile's work each).
+  if (LW.e4) {
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<sizeof(WE) == 4, f32x4, u32x2s>::type raw_t;
+    typedef const __attribute__((address_space(1))) raw_t* gsp_t;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                           // lane-derived addresses are computed HERE, not kept live over the tile loop
+    const gsp_t S = (gsp_t)(const void*)(Wp + (size_t)ntiles * WT * WT) + ln;
+    int m = stream_waves - 1 - DSS_WAVE;                   // (negative for the wave of the side job)
+    if (m >= 0 && m < nmini) {
+      raw_t cur = DSS_W_LOAD(S + m * 64);
+      for (;;) {
+        const int mn = m + stream_waves;
+        raw_t nxt = cur;
+        if (mn < nmini) nxt = DSS_W_LOAD(S + mn * 64);     // the next one is in flight under this one's butterflies
+        matvec_strip_mini(cur, m, LW.e4, nt, xs, ws, ln);
+        if (mn >= nmini) break;
+        cur = nxt;
+        m = mn;
+      }
     }
   }
   if (DSS_WAVE == 0) { DSS_ETL_WAVE_ADD(side_on ? 12 : 10) }   // tile loop of wave 0: with / without a check beside it
@@ -768,7 +874,7 @@ DSS_DEV int rayleigh_ritz(double* A, double* Vr, int m, int l, int K, double bet
 }
 
 // The whole eigen stage for ONE image (called by every thread of the owning workgroup).
-//   W          packed upper-triangular 64x64 tiles of the symmetric non-negative affinity (wsym_floats(ld) floats)
+//   W          packed upper-triangular storage of the symmetric non-negative affinity (wsym_elems(N) elements, see wsym_layout)
 //   gws        global workspace of eigs_ws_floats_per_image(ld, ncv) floats
 //   lds        LDS block of eigs_lds_layout(ld, ncv).total bytes (16-byte aligned)
 //   eigenvalues[K], eigenvectors[K, N] outputs; *info = +passes (converged) / -passes (budget exhausted)
@@ -847,6 +953,7 @@ DSS_DEV void eigs_one_image(const WE* __restrict__ W, const EigsParams P, float*
       if (check) {   // residuals of a Lanczos process fall by a bounded factor per step: far from the bar, skip checks
         const float rho = sm->rho;
         next_check = j + 1 + (rho > EIGS_SKIP2_RATIO ? 2 : (rho > EIGS_SKIP1_RATIO ? 1 : 0));
+        DSS_UNIFORM_INT(next_check);
         DSS_EIGS_RHO_TRACE(j, rho)
       }
       if (check && sm->nbad == 0) {   // Vr / theta / perm describe T_j: finish from the j-vector basis

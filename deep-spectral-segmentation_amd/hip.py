@@ -7,6 +7,7 @@ raised.  Tensors are passed as raw device pointers (``tensor.data_ptr()``), the 
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
 from pathlib import Path
@@ -397,23 +398,47 @@ def affinity_elems(n: int) -> int:
     return int(load_library().dss_affinity_elems(n))
 
 
+def wsym_layout(n: int):
+    """``(nt, ntf, e4)`` of the packed symmetric storage (csrc/eigs_core.h ``wsym_layout``): ``nt = ceil(N / 64)`` tile rows,
+    the first ``ntf`` of them stored as full 64x64 tiles (upper triangle, row-major over ``I <= J``); when the last tile
+    column holds only ``N mod 64 <= 16`` columns of the matrix it is an EDGE STRIP of ``4 e4`` columns (``e4`` = 1 or 4)
+    instead, kept as mini tiles of 64 rows x 4 columns behind the full tiles."""
+    nt, r = (n + 63) // 64, n % 64
+    if nt > 1 and 1 <= r <= 16:
+        return nt, nt - 1, (1 if r <= 4 else 4)
+    return nt, nt, 0
+
+
+@functools.lru_cache(maxsize=16)
+def _wsym_index(n: int):
+    """(rows, cols, pos): matrix coordinates and packed position of every stored element, in packed order."""
+    nt, ntf, e4 = wsym_layout(n)
+    r64 = torch.arange(64)
+    rows, cols = [], []
+    for i in range(ntf):
+        for j in range(i, ntf):
+            rows.append((64 * i + r64)[:, None].expand(64, 64).reshape(-1))
+            cols.append((64 * j + r64)[None, :].expand(64, 64).reshape(-1))
+    for m in range((ntf + 1) * e4):                       # mini tile m: tile row m // e4, edge columns 4 (m % e4) .. + 3
+        i, e = divmod(m, e4)
+        rows.append((64 * i + r64)[:, None].expand(64, 4).reshape(-1))
+        cols.append((64 * ntf + 4 * e + torch.arange(4))[None, :].expand(64, 4).reshape(-1))
+    rows, cols = torch.cat(rows), torch.cat(cols)
+    return rows, cols, torch.arange(rows.numel())         # stored elements are contiguous; only the last block is padded
+
+
 def affinity_to_dense(wp: torch.Tensor, n: int) -> torch.Tensor:
-    """Unpack ``[B, affinity_elems(N)]`` (upper-triangular 64x64 tiles) into dense symmetric ``[B, ld, ld]``
-    (diagnostics / tests; the product never materialises the dense matrix)."""
+    """Unpack ``[B, affinity_elems(N)]`` (``wsym_layout``) into dense symmetric ``[B, ld, ld]`` (diagnostics / tests; the
+    product never materialises the dense matrix)."""
     ld = affinity_ld(n)
-    nt = ld // 64
     b = wp.shape[0]
     if wp.dtype == torch.int16:   # the 16-bit fixed-point form (uint16 bits in an int16 container): w = q / 65535
         wp = (wp.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535.0
-    tiles = wp.reshape(b, -1, 64, 64)
+    rows, cols, pos = (t.to(wp.device) for t in _wsym_index(n))
     dense = torch.zeros((b, ld, ld), dtype=wp.dtype, device=wp.device)
-    t = 0
-    for i in range(nt):
-        for j in range(i, nt):
-            dense[:, 64 * i:64 * i + 64, 64 * j:64 * j + 64] = tiles[:, t]
-            if j != i:
-                dense[:, 64 * j:64 * j + 64, 64 * i:64 * i + 64] = tiles[:, t].transpose(1, 2)
-            t += 1
+    vals = wp[:, pos]
+    dense[:, cols, rows] = vals                          # the mirror image first: diagonal tiles and the corner are stored in
+    dense[:, rows, cols] = vals                          # full, and what the kernels wrote there is what is reported
     return dense
 
 
@@ -424,12 +449,12 @@ def affinity_from_dense(w: torch.Tensor) -> torch.Tensor:
     assert w.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == w.shape[2]
     b, n, _ = w.shape
     ld = affinity_ld(n)
-    nt = ld // 64
     full = torch.zeros((b, ld, ld), dtype=torch.float32, device=w.device)
     full[:, :n, :n] = w
-    tiles = full.view(b, nt, 64, nt, 64).permute(0, 1, 3, 2, 4)            # [B, ti, tj, 64, 64]
-    ti, tj = torch.triu_indices(nt, nt, device=w.device)                   # row-major over i <= j: the packed order
-    return tiles[:, ti, tj].reshape(b, -1).contiguous()
+    rows, cols, pos = (t.to(w.device) for t in _wsym_index(n))
+    out = torch.zeros((b, affinity_elems(n)), dtype=torch.float32, device=w.device)
+    out[:, pos] = full[:, rows, cols]
+    return out
 
 
 def affinity(feats: torch.Tensor, threshold_at_zero: bool = True) -> torch.Tensor:

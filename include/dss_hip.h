@@ -25,9 +25,12 @@
 extern "C" {
 #endif
 
-/* 7: + dss_lnlinear_kfeatures (D = 384 / 768, f16 / bf16 operands; round 5);  6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
+/* 8: the packed storage of W gained the EDGE STRIP (below, at dss_affinity): a caller that only passes W from dss_affinity* to
+ * dss_*_eigs* - every caller there is - is unaffected; one that builds or reads packed W itself must follow the layout of the
+ * library it runs against (dss_affinity_elems(N) tells them apart: 106 * 4096 at N = 900 with the strip, 120 * 4096 without);
+ * 7: + dss_lnlinear_kfeatures (D = 384 / 768, f16 / bf16 operands; round 5);  6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
  * only ever added: a caller built against version n runs against any library with dss_abi_version() >= n. */
-#define DSS_ABI_VERSION 7
+#define DSS_ABI_VERSION 8
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -159,10 +162,17 @@ int dss_normalize_rows(const float* x, float* y, int rows, int D, float eps, voi
  * `W / W.max()` (:194) is NOT applied: the generalized problem (D-W)v = lambda D v is invariant
  * under W -> cW; eigenvalues and eigenvectors are unchanged.
  * feats: [B, N, D] f32 (already normalised if wanted).
- * W is symmetric, so it is produced (and later streamed) as PACKED UPPER-TRIANGULAR 64x64 TILES: with
- * ld = dss_affinity_ld(N) = N rounded up to 64 and nt = ld/64, tile (I, J), J >= I, is the t-th block of
- * 4096 floats, t = I*nt - I*(I-1)/2 + (J-I), row-major inside the tile, diagonal tiles stored in full, entries
- * with row or column >= N are 0.  Per image dss_affinity_elems(N) floats: W is [B, dss_affinity_elems(N)]. */
+ * W is symmetric, so it is produced (and later streamed) as PACKED UPPER-TRIANGULAR STORAGE, in blocks of 4096 elements.  With
+ * ld = dss_affinity_ld(N) = N rounded up to 64 and nt = ld/64 tile rows:
+ *   - no edge strip (N mod 64 == 0 or > 16, or N <= 64): ntf = nt, and tile (I, J), I <= J < ntf, is block
+ *     t = I*ntf - I*(I-1)/2 + (J-I), row-major inside the 64x64 tile, diagonal tiles stored in full;
+ *   - EDGE STRIP (1 <= N mod 64 <= 16, N > 64; ABI 8): ntf = nt - 1 full tile rows / columns as above, and of the last tile
+ *     column only E = 4 (N mod 64 <= 4) or 16 columns are kept, as MINI TILES of 64 rows x 4 columns ([row][4], 256 elements):
+ *     mini tile m = I * (E/4) + e holds columns 64 ntf + 4e .. + 3 of rows 64 I .. 64 I + 63, I = 0 .. ntf (I = ntf is the
+ *     corner, stored in full); they follow the full tiles, the last block of 16 mini tiles padded (never read).
+ *     N = 900: 105 + 1 blocks instead of 120 (1.07x the N (N + 1) / 2 elements of the triangle instead of 1.21x).
+ * Entries with row or column >= N are 0.  Per image dss_affinity_elems(N) elements: W is [B, dss_affinity_elems(N)].
+ * (csrc/eigs_core.h: wsym_layout / wsym_at; dss_amd.hip.affinity_to_dense / affinity_from_dense convert.) */
 int dss_affinity_ld(int N);
 size_t dss_affinity_elems(int N);
 int dss_affinity(const float* feats, float* W, int B, int N, int D, int threshold_at_zero,

@@ -10,7 +10,7 @@
 
 #include "../../deep-spectral-segmentation_amd/csrc/eigs_core.h"
 
-// W: packed upper-triangular 64x64 tiles (csrc/eigs_core.h wsym_*), wsym_floats(ld) elements per image; WE = float
+// W: packed upper-triangular storage (csrc/eigs_core.h wsym_layout), wsym_elems(N) elements per image; WE = float
 // (the values) or uint16_t (round(65535 w), the default storage of the product path).
 template <class WE>
 static int emul(const WE* W, int B, int N, int ld, int K, float* eigenvalues, float* eigenvectors, int32_t* info,
@@ -27,7 +27,7 @@ static int emul(const WE* W, int B, int N, int ld, int K, float* eigenvalues, fl
   std::vector<float> gws(eigs_ws_floats_per_image(ld, ncv));
   for (int b = 0; b < B; ++b) {
     memset(lp, 0, L.total);
-    eigs_one_image(W + (size_t)b * wsym_floats(ld), P, gws.data(), lp, eigenvalues + (size_t)b * K,
+    eigs_one_image(W + (size_t)b * wsym_elems(N), P, gws.data(), lp, eigenvalues + (size_t)b * K,
                    eigenvectors + (size_t)b * K * N, info + b);
   }
   return 0;
@@ -43,4 +43,11 @@ extern "C" int dss_emul_laplacian_eigs_u16(const uint16_t* W, int B, int N, int 
                                            float* eigenvectors, int32_t* info, int ncv, int keep, float tol,
                                            int max_restarts) {
   return emul<uint16_t>(W, B, N, ld, K, eigenvalues, eigenvectors, info, ncv, keep, tol, max_restarts, 0);
+}
+
+// the storage layout itself, for the tests' independent restatement of it (tests/util.pack_sym)
+extern "C" long dss_emul_wsym_elems(int N) { return (long)dss::wsym_elems(N); }
+extern "C" long dss_emul_wsym_at(int N, int ti, int tj, int lr, int lc) {
+  const dss::WsymLayout L = dss::wsym_layout(N);
+  return dss::wsym_has(L, tj, lc) ? (long)dss::wsym_at(L, ti, tj, lr, lc) : -1;
 }

@@ -456,7 +456,9 @@ def test_dense_affinity_packing_round_trip_and_solver_agreement(n):
     feats = torch.from_numpy(synthetic.synthetic_features("blobs", n, 384, 5, {64: (8, 8), 196: (14, 14), 713: (23, 31)}[n])).cuda()[None]
     wp = hip.affinity_split(feats, True, True)
     dense = hip.affinity_to_dense(wp, n)
-    assert torch.equal(hip.affinity_from_dense(dense[:, :n, :n].contiguous()), wp)
+    stored = hip._wsym_index(n)[2].numel()             # the last block of edge mini tiles is padded: never read, never written
+    assert stored <= wp.shape[1] < stored + 4096
+    assert torch.equal(hip.affinity_from_dense(dense[:, :n, :n].contiguous())[:, :stored], wp[:, :stored])
     w = spectral.feature_affinity_dense(feats)
     assert w.shape == (1, n, n) and float(w.max()) == 1.0
     for problem in ("laplacian", "laplacian_unnormalized"):

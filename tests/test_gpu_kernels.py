@@ -495,7 +495,7 @@ def test_normalize_rows():
 
 
 @pytest.mark.parametrize("b,n,d", [(2, 900, 384), (1, 713, 384), (1, 16, 32), (1, 64, 64), (1, 65, 32), (3, 129, 768),
-                                    (1, 3600, 768)])
+                                    (1, 3600, 768), (2, 196, 384), (1, 80, 64), (1, 81, 64), (1, 784, 384)])
 def test_affinity_matches_fp64(b, n, d):
     feats = torch.from_numpy(np.stack([synthetic.synthetic_features("blobs" if i % 2 else "random", n, d, 50 + i,
                                                                      None if int(n ** 0.5) ** 2 == n else (1, n))
@@ -503,8 +503,9 @@ def test_affinity_matches_fp64(b, n, d):
     fn = hip.normalize_rows(feats.to(DEV))
     wp = hip.affinity(fn)
     ld = hip.affinity_ld(n)
-    nt = ld // 64
-    assert tuple(wp.shape) == (b, nt * (nt + 1) // 2 * 4096) and ld % 64 == 0 and ld >= n
+    nt, ntf, e4 = hip.wsym_layout(n)                 # full tile rows, then the edge strip's mini tiles in blocks of 16
+    assert nt == ld // 64 and (e4 > 0) == (n > 64 and 1 <= n % 64 <= 16) and ntf == nt - (e4 > 0)
+    assert tuple(wp.shape) == (b, (ntf * (ntf + 1) // 2 + ((ntf + 1) * e4 + 15) // 16) * 4096) and ld % 64 == 0 and ld >= n
     w = hip.affinity_to_dense(wp, n).cpu()           # [b, ld, ld] from the packed upper-triangular tiles
     assert torch.equal(w[:, :, n:], torch.zeros(b, ld, ld - n)) and torch.equal(w[:, n:, :], torch.zeros(b, ld - n, ld))
     x = F.normalize(feats.double(), dim=-1)
@@ -649,7 +650,8 @@ def test_eigs_batch_against_oracle(mode):
                    d=build_w64(feats[i])[1], ext=ext, lam_tol=1e-4 if mode == "fused" else 1e-5)
 
 
-@pytest.mark.parametrize("n,d,K", [(16, 32, 5), (12, 32, 3), (70, 64, 1), (70, 64, 2), (196, 384, 20), (333, 96, 7)])
+@pytest.mark.parametrize("n,d,K", [(16, 32, 5), (12, 32, 3), (70, 64, 1), (70, 64, 2), (196, 384, 20), (333, 96, 7),
+                                   (65, 32, 3), (80, 64, 4), (784, 384, 5), (128, 64, 4)])   # edge strips of 1 / 16 / 16 columns, none
 def test_eigs_edge_shapes_against_fp64(n, d, K):
     feats = synthetic.synthetic_features("random", n, d, 4000 + n + K)
     lam64, v64 = spectral_ref.dense_f64_eigs(feats, min(K + 8, n))

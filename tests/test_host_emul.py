@@ -31,13 +31,21 @@ def emul(tmp_path_factory):
 
 
 def pack_sym(w, ld):
-    """Dense [n, n] -> packed upper-triangular 64x64 tiles (include/dss_hip.h, dss_affinity)."""
+    """Dense [n, n] -> the packed symmetric storage of include/dss_hip.h (dss_affinity): the upper-triangular full 64x64
+    tiles, then - when the last tile column holds only n mod 64 <= 16 columns - the edge strip as mini tiles of 64 rows x 4
+    columns (4 columns for a remainder <= 4, else 16), padded to whole blocks of 4096 elements."""
     n = w.shape[0]
-    nt = ld // 64
+    nt, r = ld // 64, n % 64
+    ntf, e4 = (nt - 1, 1 if r <= 4 else 4) if nt > 1 and 1 <= r <= 16 else (nt, 0)
     full = np.zeros((ld, ld), np.float32)
     full[:n, :n] = w
-    tiles = [full[64 * i:64 * i + 64, 64 * j:64 * j + 64].reshape(-1) for i in range(nt) for j in range(i, nt)]
-    return np.ascontiguousarray(np.concatenate(tiles))
+    parts = [full[64 * i:64 * i + 64, 64 * j:64 * j + 64].reshape(-1) for i in range(ntf) for j in range(i, ntf)]
+    for i in range(ntf + 1 if e4 else 0):
+        for e in range(e4):
+            parts.append(full[64 * i:64 * i + 64, 64 * ntf + 4 * e:64 * ntf + 4 * e + 4].reshape(-1))
+    out = np.concatenate(parts)
+    pad = -out.size % 4096
+    return np.ascontiguousarray(np.concatenate([out, np.full(pad, np.nan if pad else 0, np.float32)]))   # padding is never read
 
 
 def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, threshold=True, u16=False):
@@ -54,7 +62,7 @@ def run_emul(lib, feats, K, ncv=0, keep=0, tol=2e-6, max_restarts=60, mode=0, th
     ev, vec, info = np.zeros(K, np.float32), np.zeros((K, n), np.float32), np.zeros(1, np.int32)
     if u16:  # the product path's storage: round(65535 w), w in [0, 1]
         assert threshold and mode == 0
-        wq = np.ascontiguousarray(np.rint(np.clip(wp, 0.0, 1.0) * 65535.0).astype(np.uint16))
+        wq = np.ascontiguousarray(np.rint(np.clip(np.nan_to_num(wp, nan=0.7), 0.0, 1.0) * 65535.0).astype(np.uint16))
         lib.dss_emul_laplacian_eigs_u16(wq.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), 1, n, ld, K,
                                         ev.ctypes.data_as(FP), vec.ctypes.data_as(FP), info.ctypes.data_as(IP), ncv,
                                         keep, tol, max_restarts)
@@ -167,3 +175,45 @@ def test_kernel_logic_odd_krylov_dimensions(emul, n, K, ncv):
     lam, vec, info = run_emul(emul, feats, K, ncv=ncv)
     assert info > 0, info
     check_eigs(vec, lam, v64[:K], lam64[:K], what=f"n{n}_K{K}_ncv{ncv}", ext=(lam64, v64))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 68, 69, 80, 81, 128, 130, 196, 400, 784, 900, 960, 1600, 3600])
+def test_packed_layout_restatements_agree(emul, n):
+    """The packed symmetric storage is stated three times - csrc/eigs_core.h (wsym_at, what the kernels use), pack_sym above
+    (numpy) and dss_amd.hip (torch, affinity_to_dense / affinity_from_dense): every stored element in the same place, sizes
+    as documented (N = 900: 105 full tiles + one block of edge mini tiles, 1.07x the triangle, where 120 tiles were 1.21x)."""
+    import torch
+    from dss_amd import hip
+    emul.dss_emul_wsym_elems.restype = ctypes.c_long
+    emul.dss_emul_wsym_at.restype = ctypes.c_long
+    ld = (n + 63) // 64 * 64
+    code = (np.arange(n, dtype=np.float32)[:, None] * 4096 + np.arange(n, dtype=np.float32)[None, :])   # exact in f32 for n <= 4096
+    code = np.maximum(code, code.T) + 1                     # symmetric, non-zero inside the matrix
+    packed = pack_sym(code, ld)
+    elems = emul.dss_emul_wsym_elems(n)
+    assert packed.size == elems == hip.affinity_elems(n)
+    expect = {900: 106, 3600: 1596 + 15, 960: 120, 64: 1, 65: 2, 196: 6 + 1, 784: 78 + 4, 1600: 325}
+    if n in expect:
+        assert elems == expect[n] * 4096
+    nt = ld // 64
+    rng = np.random.default_rng(n)
+    seen = 0
+    for ti in range(nt):
+        for tj in range(ti, nt):
+            for lr, lc in [(0, 0), (63, 3), (int(rng.integers(64)), int(rng.integers(64))), (17, 15), (5, 16), (63, 63)]:
+                pos = emul.dss_emul_wsym_at(n, ti, tj, lr, lc)
+                r, c = 64 * ti + lr, 64 * tj + lc
+                if pos < 0:                                   # not stored: only columns of the edge beyond the matrix
+                    assert c >= n and tj == nt - 1
+                    continue
+                seen += 1
+                assert 0 <= pos < elems
+                assert packed[pos] == (code[r, c] if r < n and c < n else 0.0), (n, ti, tj, lr, lc)
+    assert seen > 0
+    # torch: round trip through the packed form, and the same positions as numpy
+    w = torch.from_numpy(code)[None]
+    tp = hip.affinity_from_dense(w)
+    stored = ~np.isnan(packed)
+    assert np.array_equal(tp[0].numpy()[stored], packed[stored])
+    dense = hip.affinity_to_dense(tp, n)
+    assert dense.shape == (1, ld, ld) and torch.equal(dense[0, :n, :n], w[0]) and float(dense[0, n:].abs().sum()) == 0.0
