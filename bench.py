@@ -115,6 +115,8 @@ def parse():
                     help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
                          "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
                          "HIP-event durations behind `roofline` then overlap and read long)")
+    ap.add_argument("--shard-forwards", type=int, default=4,
+                    help="a step that is not whole forwards of --vit-batch images (a rank's shard) is cut into at least this many forwards (chunk_counts)")
     ap.add_argument("--balanced-chunks", action="store_true",
                     help="A/B arm: cut a shard step into equal forwards (round 4: 1250 = 4 x 313) instead of whole rounds of "
                          "workgroups with a one-round lead forward")
@@ -277,6 +279,9 @@ def page_lock(t: torch.Tensor, how: str = "malloc") -> torch.Tensor:
 ROUND_IMAGES = 0.0   # images whose token rows fill ONE round of the K-resident Linear kernel's workgroups (set in main)
 
 
+SHARD_FORWARDS = 4    # forwards a one-step shard is cut into at least, while they stay above 256 images (--shard-forwards)
+
+
 def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: float = -1.0):
     """Images per ViT forward of a step of ``cnt`` images.  A step that is whole forwards of ``vit_batch`` images (the
     steady state: ``vit_batch`` is sized to whole rounds of workgroups by ``vit.wave_filling_batch``) runs them as they
@@ -292,7 +297,7 @@ def chunk_counts(cnt: int, vit_batch: int, lead: bool = False, round_images: flo
     rnd = ROUND_IMAGES if round_images < 0 else round_images
     if cnt % vit_batch == 0 and not (lead and rnd > 0 and cnt == vit_batch):
         return [vit_batch] * (cnt // vit_batch)
-    n = max(1, -(-cnt // vit_batch), min(4, cnt // 256))
+    n = max(1, -(-cnt // vit_batch), min(SHARD_FORWARDS, cnt // 256))
     if rnd <= 0 or cnt < 2 * rnd or n == 1:
         per, extra = divmod(cnt, n)
         return [per + (1 if i < extra else 0) for i in range(n)]
@@ -677,9 +682,10 @@ def main():
         a.vit_batch = wave_filling_batch(n_patches + 1, target, rows_per_workgroup=rows) if rows else target
         while a.vit_batch * (n_patches + 1) > row_cap:      # (wave_filling_batch may round up to 25 % above the target)
             a.vit_batch -= 1
-    global ROUND_IMAGES
+    global ROUND_IMAGES, SHARD_FORWARDS
     rows_cu = hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 0))[1]
     ROUND_IMAGES = ncu * rows_cu / (n_patches + 1) if rows_cu and a.linear_kres and not a.balanced_chunks else 0.0   # see chunk_counts
+    SHARD_FORWARDS = max(1, a.shard_forwards)
     if a.batch <= 0:
         # the eigensolver runs one workgroup per image, two per CU: pick the number of ViT forwards per step (4..8: the
         # copy of forward j + 1 hides under forward j) whose image count best fills whole rounds of 2 x CUs workgroups

@@ -47,7 +47,9 @@ for STAGE in "$@"; do
       T=${PROF_TAG:-c2}
       declare -A PMCG=( [mfma]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
                           [wait]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES"
-                          [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" )
+                          [fetch]="FETCH_SIZE" [write]="WRITE_SIZE"
+                          [l2a]="TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
+                          [l2b]="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_GATE_EN1_sum" )
       for G in ${PMC_GROUPS:-mfma wait fetch write}; do
         rm -rf gpurun_out/pmcrun_$G && mkdir -p gpurun_out/pmcrun_$G
         (cd /tmp && timeout 600 rocprofv3 --pmc ${PMCG[$G]} --kernel-trace -d $REPO_DIR/gpurun_out/pmcrun_$G -o pmc -- python $REPO_DIR/bench.py --steps 1 --warmup 1 --min-warmup-seconds 0 --cpu-images 0 --companion-steps 0 --dino-like-steps 0 ${BENCH_ARGS:-} > $REPO_DIR/gpurun_out/pmc_${T}_$G.bench.json 2> $REPO_DIR/gpurun_out/pmcrun_$G/bench.err)
