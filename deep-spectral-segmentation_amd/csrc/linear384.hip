@@ -433,6 +433,19 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
   // the START of the next chunk's MFMA phase, right behind wait_dma + barrier where nothing younger is in flight)
   T bias_next = from_f32<T>(0.f);
   if constexpr (LNM == 0) bias_next = bias[li];
+  // LNM: aux[col] = (-sw, b) of this lane's column (hh = 0 / 1), the same way - a plain load one chunk ahead.  (Round 4 fetched it
+  // at the start of the chunk's own MFMA phase from inline asm and waited for it by count in front of the last MFMA: hipcc is
+  // free to COPY the destination register between the two asm statements, and in the last chunk's branch it did, in front of
+  // the wait - a stale correction term in the last 32 columns of a few workgroups whenever the load took longer than the
+  // MFMA phase, 1-8 launches in 300; scripts/debug/lnlinear_stress.py.  A load the compiler issues is one it waits for.)
+  auto aux_lane = [&](int c) -> float {
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));   // fresh lane id: no offset register is held
+    const unsigned aoff = ((l & 31u) << 3) | ((l >> 5) << 2);
+    return *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(aux + 2 * c * LBN) + aoff);
+  };
+  float wc_next = 0.f;
+  if constexpr (LNM != 0) wc_next = aux_lane(0);
   (void)LTHREADS;
 
   // ---- output: transpose patch per wave (32 RT rows x 128 B; 16-byte slot p of row r lives at slot
@@ -465,18 +478,14 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
     V8 f[PF + 1];
     static_for<PF>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read_b128_at<1024 * i>(f[i], wbase); });
     const float bcol = to_f32<T>(bias_next);
-    float wcorr = 0.f;
+    float wcorr = wc_next;
     if constexpr (LNM == 0) {
       if ((c + 1) * LBN < N) bias_next = bias[(c + 1) * LBN + li];
     } else {
-      // aux[col] = (-sw, b) of THIS chunk, needed by its last MFMA: requested here, awaited there by count (the NST pieces of the
-      // next W chunk are younger) - a value prefetched a chunk ahead would be a register held through the GELU epilogue,
-      // and so would its lane offset (rebuilt from v_mbcnt behind an opaque asm: 4 VALU per chunk)
-      unsigned l;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-      const unsigned aoff = ((l & 31u) << 3) | ((l >> 5) << 2);
-      const float* ap = aux + 2 * c * LBN;
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(wcorr) : "v"(aoff), "s"(ap) : "memory");
+      // this chunk's correction term arrived a chunk ago; the use pinned HERE is where hipcc puts its wait for that load - behind
+      // wait_dma + the barrier, nothing younger in flight - and not in front of the last MFMA, where the next W chunk's DMA pieces are
+      asm volatile("" : "+v"(wcorr));
+      if ((c + 1) * LBN < N) wc_next = aux_lane(c + 1);
     }
     if (stage_next >= 0) stage(stage_next);                // DMA issue behind the first fragment reads
 #pragma unroll
@@ -505,8 +514,6 @@ __device__ __forceinline__ void linear_kres_body(const T* __restrict__ A, float*
       acc0 = mfma32x32x16(fb, a_one, acc0);
       if (RT == 2) acc1 = mfma32x32x16(fb, a_one, acc1);
     } else {
-      if (stage_next >= 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wcorr) : "n"(NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcorr) :: "memory");
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcorr, am[0], acc0, 0, 0, 0);
       if (RT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcorr, am[RT - 1], acc1, 0, 0, 0);
     }

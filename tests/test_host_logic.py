@@ -443,3 +443,18 @@ def test_gelu_f16_poly_error_budget():
     for sigma, bar in ((0.7, 1.5), (1.5, 1.15), (3.0, 1.12)):
         assert nsr(y, sigma) <= bar * nsr(rounded, sigma), (sigma, nsr(y, sigma), nsr(rounded, sigma))
     assert nsr(y, 1.5) < 2.3e-4 and nsr(rounded, 1.5) > 1.8e-4
+
+
+def test_inline_asm_pipelines_are_not_copied_before_their_wait():
+    """scripts/check_async_asm.py on the compiler's assembly of the two kernels with inline-asm software pipelines: no asm
+    statement issues a register-returning global load (the round-5 race of the fused norm -> Linear kernel: hipcc copied the
+    destination register of such a load in front of the asm wait that covered it), and nothing touches the destination of an asm
+    LDS read between the read and the counted wait that covers it."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, str(REPO / "scripts" / "check_async_asm.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "linear384.s" in r.stdout and "attention.s" in r.stdout and " 0 violation(s)" in r.stdout
