@@ -162,6 +162,10 @@ def test_bench_chunking_is_balanced_and_keeps_the_copy_pipeline_fed():
     assert bench.chunk_counts(1250, 1018, True, rnd) == [88, 436, 436, 290]            # BASELINE configs[3]'s per-rank shard: 0.6 + 3 + 3 + 2 rounds
     assert bench.chunk_counts(1250, 1018, False, rnd) == [436, 290, 290, 234]
     assert bench.chunk_counts(4072, 1018, False, rnd) == [1018] * 4 == bench.chunk_counts(4072, 1018, True, rnd)
+    assert bench.chunk_counts(1250, 2473, True, rnd) == [88, 436, 436, 290]            # ... also under the round-5 default forward size
+    bench.SHARD_FORWARDS = 3                                                            # --shard-forwards: fewer, longer forwards
+    assert bench.chunk_counts(1250, 2473, True, rnd) == [88, 581, 581] and bench.chunk_counts(1250, 2473, False, rnd) == [436, 436, 378]
+    bench.SHARD_FORWARDS = 4
     assert bench.chunk_counts(2030, 290, False, rnd) == [290] * 7
     assert bench.chunk_counts(100, 1018, True, rnd) == [100] and bench.chunk_counts(600, 1018, False, 0.0) == [300, 300]
     for cnt, vb, lead in [(1, 5, False), (17, 5, True), (9999, 1018, False), (873, 291, True), (3334, 1018, True), (1018, 1018, True),
