@@ -13,10 +13,15 @@ from dss_amd import synthetic
 from dss_amd.vit import DinoViT
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+only = sys.argv[2] if len(sys.argv) > 2 else ""          # e.g. dino_vitb8: that model's configurations only
+opts = {}                                                 # e.g. linear_kres=0,fuse_ln=0,fuse_k=0: DinoViT switches (ints / bools)
+for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] else []):
+    k_, v_ = kv.split("=")
+    opts[k_] = int(v_) if k_ == "linear_kres" else bool(int(v_))
 dev = torch.device("cuda")
-for name, size, batch, dtype in [("dino_vits16", 480, 291, torch.float16), ("dino_vits16", 480, 2473, torch.float16), ("dino_vitb8", 480, 24, torch.float16),
-                                 ("dino_vitb16", 480, 256, torch.float16), ("dino_vits8", 224, 128, torch.bfloat16), ("dino_vits16", 224, 1331, torch.float16)]:
-    model = DinoViT(name, synthetic.synthetic_state_dict(name, 0), dev, dtype)
+for name, size, batch, dtype in [c for c in [("dino_vits16", 480, 291, torch.float16), ("dino_vits16", 480, 2473, torch.float16), ("dino_vitb8", 480, 24, torch.float16),
+                                 ("dino_vitb16", 480, 256, torch.float16), ("dino_vits8", 224, 128, torch.bfloat16), ("dino_vits16", 224, 1331, torch.float16)] if only in f"{c[0]}:{c[2]}"]:
+    model = DinoViT(name, synthetic.synthetic_state_dict(name, 0), dev, dtype, **opts)
     g = torch.Generator().manual_seed(7)
     img = torch.randint(0, 256, (min(batch, 64), size, size, 3), dtype=torch.uint8, generator=g).to(dev)
     img = img.repeat((batch + img.shape[0] - 1) // img.shape[0], 1, 1, 1)[:batch].contiguous()
@@ -36,6 +41,6 @@ for name, size, batch, dtype in [("dino_vits16", 480, 291, torch.float16), ("din
                 d = (out[0] != first[0]).nonzero()
                 print(f"    forward {i}: outputs equal {same}; {d.shape[0]} fp32 feature values differ, images {sorted(set(d[:, 0].tolist()))[:8]}, "
                       f"max |diff| {(out[0] - first[0]).abs().max().item():.3g}", flush=True)
-    print(f"{name} {size}x{size} batch {batch} {str(dtype)[6:]}: {bad} of {reps} forwards differ from the first  ({model.paths().get('qkv', '')[:60]})", flush=True)
+    print(f"{name} {size}x{size} batch {batch} {str(dtype)[6:]} {opts or ''}: {bad} of {reps} forwards differ from the first", flush=True)
     del model
     torch.cuda.empty_cache()
