@@ -14,6 +14,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "dino_vitb8"
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 b = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+only = sys.argv[5] if len(sys.argv) > 5 else ""           # e.g. "library GEMM": only ops whose label contains it get `reps` calls, the others one
 dev = torch.device("cuda")
 model = DinoViT(name, synthetic.synthetic_state_dict(name, 0), dev, torch.float16)
 p, d, heads = model.patch_size, model.embed_dim, model.num_heads
@@ -32,10 +33,12 @@ def stress(label, fn):
     queue stays full, as in a real forward), a library GEMM in between now and then."""
     global junk
     first = [o.clone() for o in fn()]
+    if only and only not in label:
+        return first
     bad = torch.zeros((), dtype=torch.int64, device=dev)
     worst = torch.zeros((), dtype=torch.float32, device=dev)
     for i in range(reps):
-        if i % 50 == 1:
+        if i % 500 == 1:
             junk = junk @ junk * 1e-3
         out = fn()
         diff = torch.zeros((), dtype=torch.bool, device=dev)
