@@ -36,6 +36,25 @@ def test_vit_features_match_oracle(dtype, tol, h, w):
         assert rel < tol, rel
 
 
+def test_headline_forward_is_reproducible_bit_for_bit():
+    """Every kernel of the ViT forward is deterministic (no atomics, fixed reduction orders, one library algorithm per shape), so
+    the same batch must give the same bits every time - the whole-forward form of
+    `test_lnlinear_repeated_launches_give_the_same_bits` (`scripts/debug/forward_stress.py` is the
+    long form: 0 differing forwards in 1500 for this model).  dino_vits16 at 480 x 480, the headline configuration."""
+    model = DinoViT("dino_vits16", synthetic.synthetic_state_dict("dino_vits16", 0), DEV, torch.float16)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (48, 480, 480, 3), dtype=torch.uint8, generator=g).to(DEV)
+    first = [t.clone() for t in model.extract_k_f16(img)]
+    junk = torch.randn(2048, 2048, device=DEV)
+    for i in range(30):
+        if i % 3 == 1:
+            junk = junk @ junk * 1e-3                     # another kernel in front: different clocks / cache state
+        elif i % 3 == 2:
+            torch.cuda.synchronize()                      # a cold start
+        out = model.extract_k_f16(img)
+        assert all(torch.equal(a, b) for a, b in zip(out, first)), i
+
+
 def test_patch_indexing_on_the_hip_path():
     """Row n of the features is patch (n // W_p, n % W_p), CLS dropped (extract.py:96-98; the reference-side contract
     is tests/golden/index_probe.npz): with the position embedding zeroed the ViT is equivariant to a permutation of
