@@ -462,3 +462,12 @@ def test_inline_asm_pipelines_are_not_copied_before_their_wait():
     r = subprocess.run([sys.executable, str(REPO / "scripts" / "check_async_asm.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "linear384.s" in r.stdout and "attention.s" in r.stdout and " 0 violation(s)" in r.stdout
+
+
+def test_scripts_compile():
+    """The measurement / stress scripts under scripts/ are run by hand on the GPU box: at least they must parse."""
+    import ast
+    files = sorted((REPO / "scripts").glob("*.py")) + sorted((REPO / "scripts" / "debug").glob("*.py"))
+    assert len(files) >= 10
+    for f in files:
+        ast.parse(f.read_text(), filename=str(f))
