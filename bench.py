@@ -443,7 +443,9 @@ def summarize_timers(timers, n_patches, dim, depth_attn, affinity_mode="fused"):
                 if ai * HBM_PEAK_GBS / 1e3 < MFMA16_PEAK_TF:
                     entry.update(bound="hbm", achieved=hbm / (avg * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
                 entry.update(flop_per_byte=round(ai, 1), attainable_TFs=round(min(MFMA16_PEAK_TF, ai * HBM_PEAK_GBS / 1e3), 1),
-                             mfma_TFs=round(tfs, 1), frac_mfma=round(tfs / MFMA16_PEAK_TF, 4))
+                             mfma_TFs=round(tfs, 1), frac_mfma=round(tfs / MFMA16_PEAK_TF, 4),
+                             # (`frac` changed meaning in round 5 - both views now carry their own, unambiguous key)
+                             hbm_GBs=round(hbm / (avg * 1e-3) / 1e9, 1), frac_hbm=round(hbm / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             elif name == "lnlinear_kfeatures":
                 # HBM-bound: x f32 (+ the pending branch output f16) in, fp32 + f16 features and the norms out (CLS rows dropped)
                 hbm = np.mean([m["m"] * m["k"] * (6.0 if m["res"] else 4.0) + (m["m"] - m["m"] // m["t"]) * (6.0 * m["n"] + 4.0) for m in metas])
@@ -799,7 +801,7 @@ def main():
             roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                         "unit": d["unit"], "frac": d["frac"],
                         # (the fused norm -> Linear kernel: arithmetic intensity below the ridge - both sides of its roofline)
-                        **({k_: d[k_] for k_ in ("flop_per_byte", "attainable_TFs", "mfma_TFs", "frac_mfma") if k_ in d}),
+                        **({k_: d[k_] for k_ in ("flop_per_byte", "attainable_TFs", "mfma_TFs", "frac_mfma", "hbm_GBs", "frac_hbm") if k_ in d}),
                         "traffic": traffic[0] if traffic else None,
                         "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE)*1024", "traffic_source": traffic[1] if traffic else None,
                         "timed": f"HIP events around every {max(a.timer_sample, 1)}-th launch inside the timed region"}
@@ -859,6 +861,18 @@ def main():
         e2, _, _, _, chunk_pos = run_steps(model, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, other,
                                            first_chunk=chunk_pos)
         out[f"value_w_{other}"] = round(a.companion_steps * a.batch / e2, 2)
+    if world == 1 and a.companion_steps > 0 and a.dataset == 0 and model.gelu == "erf_f16":
+        # the headline with DINO's exact erf-GELU in fp32 arithmetic instead of the packed-f16 polynomial form (both numbers
+        # on the line; `extract_features --gelu erf` is this model)
+        me = DinoViT(a.model, sd, dev, dtype, gelu="erf", linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning,
+                     fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
+        for i in range(2):
+            warm_step(me, a.w_dtype)
+        torch.cuda.synchronize()
+        e4, _, _, _, chunk_pos = run_steps(me, feeder, [a.batch] * a.companion_steps, a, rank, world, n_patches, a.w_dtype,
+                                           first_chunk=chunk_pos)
+        out["value_gelu_erf"] = round(a.companion_steps * a.batch / e4, 2)
+        del me
     if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it

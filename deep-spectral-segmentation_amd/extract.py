@@ -201,6 +201,9 @@ class _AsyncSaver:
         self.waited = 0
         self.pool.shutdown()
 
+    def abort(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
 
 class _FastSaver:
     """The savers of a LARGE run (round 5): torch-free worker processes (``pthfast.save_chunk / save_eigs / save_pngs`` - the
@@ -290,6 +293,15 @@ class _FastSaver:
         except BaseException:
             self.pool.__exit__(RuntimeError, None, None)
             raise
+        finally:
+            for slot in range(self.RING):
+                self._free(slot)
+
+    def abort(self):
+        """The run failed (worker / GPU / decode error, Ctrl-C): stop the workers and give the page-locked /dev/shm blocks back
+        NOW - `_sweep_stale` would only collect them hours later (up to RING blocks of ~0.8 GB each)."""
+        try:
+            self.pool.__exit__(RuntimeError, None, None)
         finally:
             for slot in range(self.RING):
                 self._free(slot)
@@ -660,8 +672,10 @@ def _feature_dict(k: torch.Tensor, index: int, file: str, model_name: str, patch
 
 def extract_features(images_list: str, images_root: Optional[str], model_name: str, batch_size: int,
                      output_dir: str, which_block: int = -1, weights: Optional[str] = None,
-                     dtype: str = "float16", synthetic_weights: Optional[int] = None):
-    """Extract features from a list of images (see module docstring).  ``batch_size`` is the maximum
+                     dtype: str = "float16", synthetic_weights: Optional[int] = None, gelu: str = "erf_f16"):
+    """Extract features from a list of images (see module docstring).  ``gelu``: "erf_f16" (default: erf-GELU as a polynomial
+    form on packed f16, f16 operands only) or "erf" (DINO's exact GELU in fp32 arithmetic, ~4 % slower); the run prints which one
+    and which operand dtype produced its files.  ``batch_size`` is the maximum
     number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
     whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76).  ``batch_size <= 0``: as many images as
     fill FOUR whole rounds of the Linear kernels' workgroups at the first image's size (581 at 480 x 480 / patch 16) - a
@@ -694,9 +708,13 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
     # ~6.5 ms of PIL per 480 x 480 JPEG (150 images/s per process): the ViT takes 12 000 images/s, the feature savers
     # ~1 000 files/s each - dozens of decoders (started in waves of twelve, _StaggeredPool) before the GPU is what waits
     decoders = _io_processes(len(todo), most=48) if saver.procs else 0
-    with clock("model"):
-        model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
-                                                  weights=weights, synthetic_seed=synthetic_weights)
+    try:
+        with clock("model"):
+            model, _, patch_size, _ = utils.get_model(model_name, device=device, dtype=_DTYPES[str(dtype).lower()],
+                                                      weights=weights, synthetic_seed=synthetic_weights, gelu=gelu)
+    except BaseException:
+        saver.abort()      # (the saver processes were started first: a bad checkpoint path must not leave them behind)
+        raise
 
     # One batch travels: page-locked decoded images -> async H2D + ViT -> a drain thread that waits for the batch, copies
     # the features into a page-locked shared-memory block the saver processes map and hands the files over.  The main
@@ -770,42 +788,71 @@ def extract_features(images_list: str, images_root: Optional[str], model_name: s
 
     # Real datasets (VOC) mix image sizes: bucket by shape so every ViT launch is a full same-shape batch.  At most
     # `max_pending` decoded images wait in the buckets; beyond that the fullest bucket is flushed early.
+    # The batch size is PER SHAPE BUCKET (a dataset's first image says nothing about the others): `batch_size <= 0` gives each
+    # shape four rounds of the K-resident Linear kernels' workgroups, and every bucket is clamped to the kernels' 32-bit row
+    # limits (`bucket_batch`: M * 4 D and M * T below 2^32, the formula bench.py applies).  What waits in the buckets is bounded
+    # in BYTES of decoded images (`max_pending_bytes`), not in images.
     buckets: Dict[Tuple[int, ...], List[Tuple[int, Path, torch.Tensor, str]]] = {}
     auto_bs = bs <= 0
-    bs = max(1, bs) if not auto_bs else 512
-    max_pending, n_pending = 8 * bs, 0
-    decoded = _iter_images(dataset, todo, decoders, 4 * bs, device)
-    for idx, out in todo:
-        with clock("wait for decoded image"):
-            img, file = next(decoded)
-        if auto_bs:      # sized on the first image: four rounds of 2 x CUs workgroups of the K-resident Linear kernels
-            tokens = (img.shape[0] // patch_size) * (img.shape[1] // patch_size) + 1
-            rows = spectral.hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 256))[1]
-            cus = torch.cuda.get_device_properties(device).multi_processor_count
-            bs = max(8, int(4 * cus * rows / tokens))
-            max_pending, auto_bs = 8 * bs, False
-        bucket = buckets.setdefault(tuple(img.shape), [])
-        bucket.append((idx, out, img, file))
-        n_pending += 1
-        if len(bucket) >= bs:
-            n_pending -= len(bucket)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    rows_wg = spectral.hip.LINEAR_KRES_WIDTHS.get(model.embed_dim, (None, 256))[1]
+    bs_of: Dict[Tuple[int, ...], int] = {}
+
+    def bucket_bs(shape) -> int:
+        if shape not in bs_of:
+            bs_of[shape] = bucket_batch(shape[0], shape[1], patch_size, model.embed_dim, bs if not auto_bs else 0, cus, rows_wg)
+        return bs_of[shape]
+
+    max_pending_bytes, pending_bytes = 6 << 30, 0
+    decoded = _iter_images(dataset, todo, decoders, 4 * (max(1, bs) if not auto_bs else 512), device)
+    try:
+        for idx, out in todo:
+            with clock("wait for decoded image"):
+                img, file = next(decoded)
+            shape = tuple(img.shape)
+            bucket = buckets.setdefault(shape, [])
+            bucket.append((idx, out, img, file))
+            pending_bytes += img.numel()
+            if len(bucket) >= bucket_bs(shape):
+                pending_bytes -= sum(b[2].numel() for b in bucket)
+                flush(bucket)
+            elif pending_bytes >= max_pending_bytes:
+                fullest = max(buckets.values(), key=lambda b: sum(x[2].numel() for x in b))
+                pending_bytes -= sum(b[2].numel() for b in fullest)
+                flush(fullest)
+        for bucket in buckets.values():
             flush(bucket)
-        elif n_pending >= max_pending:
-            fullest = max(buckets.values(), key=len)
-            n_pending -= len(fullest)
-            flush(fullest)
-    for bucket in buckets.values():
-        flush(bucket)
-    with clock("tail: drain thread"):
-        drain_q.put(None)
-        drainer.join()
-    if drain_err:
-        raise drain_err[0]
-    with clock("tail: savers finish"):
-        saver.close()
+        with clock("tail: drain thread"):
+            drain_q.put(None)
+            drainer.join()
+        if drain_err:
+            raise drain_err[0]
+        with clock("tail: savers finish"):
+            saver.close()
+    except BaseException:
+        # decode / GPU / worker error or Ctrl-C: the drain thread is told to stop, the workers are stopped and the page-locked
+        # /dev/shm ring is unlinked before the error leaves (the blocks used to stay until the 6 h stale sweep)
+        try:
+            drain_q.put_nowait(None)
+        except Exception:
+            pass
+        saver.abort()
+        raise
     clock.report("extract_features")
     _barrier()
     print(f"Saved features to {output_dir}")
+
+
+def bucket_batch(h: int, w: int, patch_size: int, embed_dim: int, batch_size: int, compute_units: int = 256,
+                 rows_per_workgroup: int = 256) -> int:
+    """Images per ViT forward for a bucket of ``h x w`` images.  ``batch_size > 0`` is the caller's value; ``<= 0`` asks for four
+    rounds of the K-resident Linear kernels' workgroups at THIS shape.  Either way clamped so that the forward's token matrix stays
+    inside the kernels' 32-bit limits (``M * 4 D`` bytes of the fp32 residual stream and ``M * T`` of the hand-over kernel's
+    row -> image division, both below 0.9 * 2^32: the same cap as bench.py's ``row_cap``)."""
+    tokens = (h // patch_size) * (w // patch_size) + 1
+    row_cap = int(0.9 * 2 ** 32 / max(4 * embed_dim, tokens))
+    want = int(batch_size) if batch_size > 0 else max(8, int(4 * compute_units * rows_per_workgroup / tokens))
+    return max(1, min(want, row_cap // tokens))
 
 
 def _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor, patch_size) -> str:
@@ -1016,44 +1063,48 @@ def extract_eigs(images_root: str, features_dir: str, output_dir: str, which_mat
         saver = _FastSaver(min(nproc, 8)) if nproc > 0 and which_matrix != "affinity" else _AsyncSaver()
     loaded = _iter_features(mine, which_features, nproc, 4 * bs, device)
     scheduled = set()
-    while True:
-        with clock("wait for loaded features"):
-            nxt = next(loaded, None)
-        if nxt is None:
-            break
-        data_dict, feats = nxt
-        image_id = data_dict["file"][:-4]
-        output_file = str(Path(output_dir) / f"{image_id}.pth")
-        # the reference writes synchronously, so a second feature file naming the same image finds the first one's
-        # output and is skipped (extract.py:141-146); here the first may still be in flight: remember what is scheduled
-        pngs_there = all(Path(dd, f"{image_id}.png").is_file() for dd in (single_region_dir, multi_region_dir) if dd)
-        if output_file in scheduled or (Path(output_file).is_file() and pngs_there):
-            print(f"Skipping existing file {str(output_file)}")
-            continue
-        if Path(output_file).is_file():   # an earlier run wrote the eigen file but not the requested PNGs: redo both
-            print(f"[dss] {image_id}: eigen file exists but a requested segmentation PNG does not - recomputing")
-        scheduled.add(output_file)
-        problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
-                                     data_dict["patch_size"])
-        utils.get_image_sizes(data_dict)
-        up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
-        # same feature shape, same resize target AND same grid (20 x 30 and 30 x 20 patches have the same N) share a launch
-        key = (tuple(feats.shape), up, _lr_grid(data_dict, image_downsample_factor))
-        pending.setdefault(key, []).append((output_file, feats))
-        pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
-        problems[key] = problem
-        n_pending += 1
-        if len(pending[key]) < bs and n_pending >= max_pending:
-            key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
-        if len(pending[key]) >= bs or n_pending >= max_pending:
-            n_pending -= len(pending[key])
+    try:
+        while True:
+            with clock("wait for loaded features"):
+                nxt = next(loaded, None)
+            if nxt is None:
+                break
+            data_dict, feats = nxt
+            image_id = data_dict["file"][:-4]
+            output_file = str(Path(output_dir) / f"{image_id}.pth")
+            # the reference writes synchronously, so a second feature file naming the same image finds the first one's
+            # output and is skipped (extract.py:141-146); here the first may still be in flight: remember what is scheduled
+            pngs_there = all(Path(dd, f"{image_id}.png").is_file() for dd in (single_region_dir, multi_region_dir) if dd)
+            if output_file in scheduled or (Path(output_file).is_file() and pngs_there):
+                print(f"Skipping existing file {str(output_file)}")
+                continue
+            if Path(output_file).is_file():   # an earlier run wrote the eigen file but not the requested PNGs: redo both
+                print(f"[dss] {image_id}: eigen file exists but a requested segmentation PNG does not - recomputing")
+            scheduled.add(output_file)
+            problem = _check_eig_options(which_matrix, lapnorm, image_color_lambda, image_downsample_factor,
+                                         data_dict["patch_size"])
+            utils.get_image_sizes(data_dict)
+            up = _upsample_spec(data_dict, which_matrix, image_downsample_factor)
+            # same feature shape, same resize target AND same grid (20 x 30 and 30 x 20 patches have the same N) share a launch
+            key = (tuple(feats.shape), up, _lr_grid(data_dict, image_downsample_factor))
+            pending.setdefault(key, []).append((output_file, feats))
+            pending_ids.setdefault(key, []).append((image_id, _lr_grid(data_dict, image_downsample_factor)))
+            problems[key] = problem
+            n_pending += 1
+            if len(pending[key]) < bs and n_pending >= max_pending:
+                key = max(pending, key=lambda k: len(pending[k]))   # flush the fullest bucket early
+            if len(pending[key]) >= bs or n_pending >= max_pending:
+                n_pending -= len(pending[key])
+                with clock("run batches"):
+                    run(key)
+        for key in list(pending):
             with clock("run batches"):
                 run(key)
-    for key in list(pending):
-        with clock("run batches"):
-            run(key)
-    with clock("tail: savers finish"):
-        saver.close()
+        with clock("tail: savers finish"):
+            saver.close()
+    except BaseException:
+        saver.abort()        # stop the workers, unlink the /dev/shm ring before the error leaves
+        raise
     clock.report("extract_eigs")
     _barrier()
 

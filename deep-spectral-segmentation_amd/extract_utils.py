@@ -92,10 +92,12 @@ def find_weights(name: str) -> Optional[Path]:
 
 
 def get_model(name: str, device: Optional[torch.device] = None, dtype: torch.dtype = torch.float16,
-              weights: Optional[str] = None, synthetic_seed: Optional[int] = None):
+              weights: Optional[str] = None, synthetic_seed: Optional[int] = None, gelu: str = "erf_f16"):
     """Returns ``(model, val_transform, patch_size, num_heads)`` like the reference.  ``weights``: path
     to a DINO checkpoint; otherwise ``$DSS_DINO_WEIGHTS`` / the torch.hub cache are searched.
-    ``synthetic_seed`` (or ``$DSS_SYNTHETIC_WEIGHTS``) builds random-init weights instead."""
+    ``synthetic_seed`` (or ``$DSS_SYNTHETIC_WEIGHTS``) builds random-init weights instead.  ``gelu``: ``DinoViT``'s
+    switch - "erf" is DINO's exact GELU in fp32 arithmetic, "erf_f16" (default) the same function as a polynomial
+    form on packed f16 in fc1's epilogue (csrc/kres.h; error budget in tests/test_host_logic.py)."""
     from .vit import DinoViT, load_dino_state_dict
 
     name = name.lower()
@@ -118,7 +120,9 @@ def get_model(name: str, device: Optional[torch.device] = None, dtype: torch.dty
         sd = load_dino_state_dict(str(found))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    model = DinoViT(name, sd, device, dtype)
+    model = DinoViT(name, sd, device, dtype, gelu=gelu)
+    # which arithmetic produced the files of this run (a feature directory must be attributable)
+    print(f"[dss] {name}: operands {str(dtype)[6:]}, fp32 accumulation / residual stream; GELU '{model.gelu}' = {model.paths()['gelu']}")
     return model, get_transform(name), model.patch_size, model.num_heads
 
 

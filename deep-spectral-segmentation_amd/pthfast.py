@@ -155,9 +155,27 @@ class PthFile:
 _BLOCKS: Dict[str, Tuple[mmap.mmap, int]] = {}
 
 
+def _block_slot(path: str) -> str:
+    """`dss_<owner>_s<slot>_<nbytes>` -> `dss_<owner>_s<slot>`: the ring slot a block path belongs to (a slot that GROWS gets a new
+    path; the mapping of its old, already unlinked block must go or its tmpfs pages stay allocated in every worker)."""
+    head, _, tail = path.rpartition("_")
+    return head if tail.isdigit() and head else path
+
+
 def _block(path: str, size: int) -> mmap.mmap:
     hit = _BLOCKS.get(path)
     if hit is None or hit[1] != size:
+        slot = _block_slot(path)
+        for old in [k for k in _BLOCKS if k != path and _block_slot(k) == slot]:   # the slot was re-created at another size
+            try:
+                _BLOCKS.pop(old)[0].close()
+            except (BufferError, ValueError):   # an exported view is still alive: dropped with it
+                pass
+        if hit is not None:
+            try:
+                hit[0].close()
+            except (BufferError, ValueError):
+                pass
         fd = os.open(path, os.O_RDWR)
         try:
             hit = (mmap.mmap(fd, size), size)

@@ -1,0 +1,165 @@
+"""GPU (-m gpu): every hand-written kernel launched 300 times on the same inputs at the shapes the bench uses, bits compared.
+
+Why: the one race found so far (round 5: a register copy in front of its `s_waitcnt` in the fused
+norm -> Linear kernel, wrong values in ~1 % of launches) lived in the default path for a whole round because 32-image parity
+checks do not see 1e-2-rate races.  None of these kernels has an atomic or a launch-dependent reduction order (the
+eigensolver excepted, see its test), so any differing bit is a race.  The comparison stays on the device (one counter, read once
+per kernel): the queue stays full, as in a real forward, and another kernel / a cold start goes in front of some launches.
+The long forms are scripts/debug/{kernel_stress,forward_stress,forward_bisect}.py."""
+import numpy as np
+import pytest
+import torch
+
+import dss_amd  # noqa: F401
+from dss_amd import hip, synthetic
+from dss_amd.vit import DinoViT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REPS = 300
+
+
+def stress(fn, reps=REPS):
+    """`reps` calls of `fn` (returns a list of tensors); (calls whose outputs differ from the first call's, worst |difference|)."""
+    first = [o.clone() for o in fn()]
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    worst = torch.zeros((), dtype=torch.float32, device=DEV)
+    junk = torch.randn(2048, 2048, device=DEV)
+    for i in range(reps):
+        if i % 50 == 7:
+            junk = junk @ junk * 1e-3          # another kernel in front: different clocks / cache state
+        elif i % 50 == 31:
+            torch.cuda.synchronize()           # a cold start
+        out = fn()
+        diff = torch.zeros((), dtype=torch.bool, device=DEV)
+        for a, c in zip(out, first):
+            ne = a != c
+            diff |= ne.any()
+            worst = torch.maximum(worst, ((a.float() - c.float()).abs() * ne).max())
+        bad += diff
+    return int(bad), float(worst)
+
+
+def _rand(shape, seed, dtype=torch.float16, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("b,t,heads,planar", [(290, 901, 6, True), (8, 3601, 12, True), (8, 3601, 12, False), (640, 197, 6, True)])
+def test_attention_repeated_launches_give_the_same_bits(b, t, heads, planar):
+    """attn_fwd_kernel: LDS-DMA stages behind `s_waitcnt vmcnt(0)` + barrier, the asm-pinned K-fragment pipeline
+    (`kfrag_read` / `kfrag_wait`), the transpose patch over the stage buffers."""
+    d = 64 * heads
+    qkv = _rand((3 * heads, b * t, 64), 1, scale=1.5) if planar else _rand((b, t, 3 * d), 1, scale=1.5)
+    fn = (lambda: [hip.attention(qkv, heads, 0.125, planar_bt=(b, t))]) if planar else (lambda: [hip.attention(qkv, heads, 0.125)])
+    assert stress(fn) == (0, 0.0)
+
+
+@pytest.mark.parametrize("m,n,k,gelu,planar", [(901 * 290, 1152, 384, 0, True), (901 * 290, 1536, 384, 2, False),
+                                               (3601 * 16, 2304, 768, 0, True), (3601 * 16, 3072, 768, 2, False)])
+def test_lnlinear_repeated_launches_at_the_forward_shapes(m, n, k, gelu, planar):
+    """dss_lnlinear_k384 / _k768 as the forward calls them: norm1 -> qkv with planar output (at D = 768 the `fuse_qkv768` path the
+    round-5 advisor flagged), norm2 -> fc1 + packed-f16 GELU.  x is updated in place: every call gets a fresh copy."""
+    g = torch.Generator().manual_seed(k + n)
+    x0 = _rand((m, k), 2, torch.float32, 2.0)
+    r = _rand((m, k), 3)
+    w, bias = torch.randn(n, k, generator=g) * 0.05, torch.randn(n, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), torch.float16)
+    x = torch.empty_like(x0)
+
+    def fn():
+        x.copy_(x0)
+        return [hip.lnlinear(x, r, wg, aux, 1e-6, gelu=gelu, planar=planar), x]
+    assert stress(fn) == (0, 0.0)
+
+
+@pytest.mark.parametrize("m,n,k,planar", [(901 * 290, 384, 384, True), (901 * 290, 1152, 384, True), (3601 * 16, 768, 768, False)])
+def test_linear_kres_repeated_launches_give_the_same_bits(m, n, k, planar):
+    """dss_linear_k384 / _k768 with a given A (attn.proj of the D = 384 models; the double-buffered plain prologue)."""
+    g = torch.Generator().manual_seed(n)
+    a = _rand((m, k), 4)
+    w, bias = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV), (torch.randn(n, generator=g) * 0.1).half().to(DEV)
+    assert stress(lambda: [hip.linear_kres(a, w, bias, planar=planar)]) == (0, 0.0)
+
+
+@pytest.mark.parametrize("b,t,k", [(290, 901, 384), (16, 3601, 768)])
+def test_lnlinear_kfeatures_repeated_launches_give_the_same_bits(b, t, k):
+    """kfeat_kres_kernel: the hooked block's norm1 -> K projection -> CLS drop / f16 copy / inverse norms."""
+    g = torch.Generator().manual_seed(t)
+    x = _rand((b, t, k), 5, torch.float32, 2.0)
+    r = _rand((b, t, k), 6)
+    w, bias = torch.randn(k, k, generator=g) * 0.05, torch.randn(k, generator=g) * 0.1
+    wg, aux = hip.lnlinear_prepare(w.to(DEV), bias.to(DEV), torch.ones(k, device=DEV), torch.zeros(k, device=DEV), torch.float16)
+    assert stress(lambda: list(hip.lnlinear_kfeatures(x, r, wg, aux, 1e-6))) == (0, 0.0)
+
+
+def test_patch_embed16_repeated_launches_give_the_same_bits():
+    """patch_embed_kres_kernel: transform + PatchEmbed(16) + position rows from the u8 image."""
+    b, h, w, d = 290, 480, 480, 384
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (b, h, w, 3), dtype=torch.uint8, generator=g).to(DEV)
+    wp, bp = hip.patch_embed16_prepare((torch.randn(d, 3, 16, 16, generator=g) * 0.02).to(DEV), torch.zeros(d, device=DEV), torch.float16)
+    pos = (_rand((900, d), 9, torch.float32, 0.02) + bp).contiguous()
+    x = torch.zeros((b, 901, d), dtype=torch.float32, device=DEV)
+
+    def fn():
+        hip.patch_embed16(img, wp, None, pos, x)
+        return [x]
+    assert stress(fn) == (0, 0.0)
+
+
+@pytest.mark.parametrize("b,n,d", [(512, 900, 384), (16, 3600, 768)])
+def test_affinity_f16_repeated_launches_give_the_same_bits(b, n, d):
+    """gram_f16_dma_kernel (LDS-DMA panels, packed 16-bit W) behind the hand-over."""
+    k16 = _rand((b, n, d), 10)
+    rn = (1.0 / k16.float().norm(dim=-1)).contiguous()
+    assert stress(lambda: [hip.affinity_f16_u16(k16, rn)], reps=100 if n > 2000 else REPS) == (0, 0.0)
+
+
+def test_preprocess_and_layernorm_repeated_launches_give_the_same_bits():
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (24, 480, 480, 3), dtype=torch.uint8, generator=g).to(DEV)
+    assert stress(lambda: [hip.preprocess_patchify(img, 8, torch.float16)]) == (0, 0.0)
+    x0, r = _rand((3601 * 8, 768), 12, torch.float32, 2.0), _rand((3601 * 8, 768), 13)
+    gamma, beta = torch.ones(768, device=DEV), torch.zeros(768, device=DEV)
+    x = torch.empty_like(x0)
+
+    def fn():
+        x.copy_(x0)
+        return [hip.layernorm(x, gamma, beta, 1e-6, torch.float16, residual=r), x]
+    assert stress(fn) == (0, 0.0)
+
+
+@pytest.mark.parametrize("n,d,K,b", [(900, 384, 5, 512), (3600, 768, 15, 8)])
+def test_laplacian_eigs_repeated_launches_agree_to_rounding(n, d, K, b):
+    """laplacian_eigs_kernel: its LDS float atomics (the matvec's column sums) make it reproducible to ROUNDING, not bitwise -
+    documented bound 1e-7 in the eigenvalues and in 1 - |cos| of every eigenvector against the first launch."""
+    feats = torch.from_numpy(np.stack([synthetic.synthetic_features("blobs", n, d, 300 + i) for i in range(min(b, 16))]))
+    feats = feats.repeat((b + feats.shape[0] - 1) // feats.shape[0], 1, 1)[:b].to(DEV)
+    w = hip.affinity_fused_u16(feats)
+    ev0, vec0, info0 = hip.laplacian_eigs(w, n, K)
+    assert bool((info0 > 0).all())
+    worst_ev = torch.zeros((), device=DEV)
+    worst_cos = torch.zeros((), device=DEV)
+    for i in range(100):
+        ev, vec, info = hip.laplacian_eigs(w, n, K)
+        worst_ev = torch.maximum(worst_ev, (ev - ev0).abs().max())
+        cos = (vec * vec0).sum(-1).abs() / (vec.norm(dim=-1) * vec0.norm(dim=-1))
+        gap = (ev0[:, 1:] - ev0[:, :-1]).abs()               # a near-degenerate pair may rotate: judged on isolated vectors only
+        lone = torch.ones_like(cos, dtype=torch.bool)
+        lone[:, 1:] &= gap > 1e-4
+        lone[:, :-1] &= gap > 1e-4
+        worst_cos = torch.maximum(worst_cos, ((1.0 - cos) * lone).max())
+        assert bool((info > 0).all())
+    assert float(worst_ev) <= 1e-6 and float(worst_cos) <= 1e-6, (float(worst_ev), float(worst_cos))
+
+
+def test_vitb8_forward_is_reproducible_bit_for_bit():
+    """The D = 768 whole-forward form: dino_vitb8 at 480 x 480 (T = 3601), 24 images, 300 forwards - the
+    configuration whose forward differed twice in ~1 600 in round 5 (profiles/r05_forward_stress.txt); what was found and what
+    was changed is in DESIGN.md section 0 and profiles/r06_forward_stress.txt.  The comparison stays on the device."""
+    model = DinoViT("dino_vitb8", synthetic.synthetic_state_dict("dino_vitb8", 0), DEV, torch.float16)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (24, 480, 480, 3), dtype=torch.uint8, generator=g).to(DEV)
+    assert stress(lambda: list(model.extract_k_f16(img))) == (0, 0.0)

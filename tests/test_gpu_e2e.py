@@ -264,8 +264,10 @@ def test_config5_upper_size_range_640_vitb8_k20():
 # K = 20 on dino_vitb8 features: eigenvalues 8..36 of these images lie within a few 1e-4 of each other (bulk edge), and on such
 # problems the reference's fp32 ARPACK output misses the 1e-5 bar on the barely-isolated vectors in most draws - which images do is
 # decided by perturbations of 1e-7 in the features (round 4: 1 of 6 legs on the fp64 substitute, round 5: 3 of 6, same kernels
-# bar one operand-rounding change).  The fp64 solution is the stricter target; the tally is printed and recorded, not bounded.
-@pytest.mark.oracle_substitute(max_share=1.0)
+# bar one operand-rounding change).  The fp64 solution is the stricter target; the tally is printed, recorded AND bounded: at most
+# half of the legs may fall on the substitute (round 5 lifted the bound altogether - a drift away from the reference's own output
+# would then only have shown in a printed line; GPUTEST_r05: 5 of 6 on ARPACK).
+@pytest.mark.oracle_substitute(max_share=0.5)
 def test_config5_vitb8_mixed_sizes_k20_through_the_cli(tmp_path):
     """BASELINE config 5's single-GPU content: dino_vitb8, MIXED image sizes in the 320-640 px range (non-multiples of 8
     included), K=20, f16-operand features + fp32 eigensolve, through the two CLI stages (shape buckets, per-image B=1
@@ -673,6 +675,34 @@ def test_fp16_path_survives_dino_like_outlier_activations(name, h, w, K):
     ce = check_eigs(vec[0].cpu().numpy(), ev[0].cpu().numpy(), v.numpy(), lam.numpy(), what=f"outliers {name}",
                     lam_tol=2e-3, d=build_w64(kr[0].numpy())[1], ext=ext, report=report)
     print(f"[outliers] {name}: feature rel err {rel:.2e}, max per-vector cos err {ce.max():.2e}, clusters {report}")
+
+
+@pytest.mark.parametrize("name,h,w,K,b", [("dino_vits16", 480, 480, 5, 8), ("dino_vitb8", 224, 160, 4, 4)])
+def test_gelu_f16_form_against_the_exact_form_end_to_end(name, h, w, K, b):
+    """The default GELU of the f16 path is a polynomial form on packed f16 (csrc/kres.h, `DinoViT(gelu="erf_f16")`; max error 1.1e-3 =
+    up to 2.1 f16 spacings against the exact function, tests/test_host_logic.py::test_gelu_f16_poly_error_budget); DINO's own is the
+    exact erf form (`gelu="erf"`, one flag away: `extract_features --gelu erf`).  The end-to-end GATE for keeping it the default
+    (ADVICE r5): on DINO-like weights (outlier channels, peaked attention, wide fc1 pre-activations) AND on plain random weights the
+    two models' K features agree far inside the f16 path's own distance from the fp32 oracle, and their eigenvectors inside the
+    1e-4 bar with every cluster compared as a subspace - a fp64 reference is built from the exact-form model's features."""
+    from oracle import spectral_ref
+    imgs = torch.from_numpy(np.stack([synthetic.synthetic_image(40 + i, h, w) for i in range(b)])).to(DEV)
+    for kind, sd in (("dino-like", synthetic.dino_like_state_dict(name, 3)), ("random", synthetic.synthetic_state_dict(name, 0))):
+        exact, fast = DinoViT(name, sd, DEV, torch.float16, gelu="erf"), DinoViT(name, sd, DEV, torch.float16, gelu="erf_f16")
+        assert exact.gelu == "erf" and fast.gelu == "erf_f16" and "packed f16" in fast.paths()["gelu"]
+        ke, eve, vece, infoe = pipeline.features_and_eigs(exact, imgs, K)
+        kf, evf, vecf, infof = pipeline.features_and_eigs(fast, imgs, K)
+        assert bool((infoe > 0).all()) and bool((infof > 0).all())
+        rel = ((kf - ke).flatten(1).norm(dim=1) / ke.flatten(1).norm(dim=1)).max().item()
+        assert rel < 1.5e-3, (kind, rel)       # (the f16 path as a whole is held to 6e-3 from the fp32 oracle on these weights)
+        worst = 0.0
+        for i in range(b):
+            lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(ke[i:i + 1].cpu(), K, max_draws=0)   # fp64 solution of the exact-form features
+            ce = check_eigs(vecf[i].cpu().numpy(), evf[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"gelu forms {name} {kind} {i}",
+                            lam_tol=2e-3, d=build_w64(ke[i].cpu().numpy())[1], ext=ext)
+            worst = max(worst, float(ce.max()))
+        print(f"[gelu forms] {name} {kind}: features differ by {rel:.2e} (relative, worst image); eigenvector check passed, "
+              f"worst per-vector cos err {worst:.2e}")
 
 
 def test_loader_reads_a_full_dino_training_checkpoint(tmp_path):

@@ -310,6 +310,44 @@ def test_file_io_worker_processes_round_trip(tmp_path):
     bad.submit_features(0, [(0, (2, 2), 0, "x.jpg", "m", 16, (1, 3, 4, 4), str(tmp_path / "no_dir" / "x.pth"))])
     with pytest.raises(Exception):
         bad.close()
+    # a run that FAILS gives its /dev/shm ring back at once (the blocks used to wait for the 6 h stale sweep) ...
+    dead = extract._FastSaver(1)
+    dead.block(0, 4096), dead.block(3, 8192)
+    mine = lambda: [n for n in os.listdir("/dev/shm") if n.startswith(f"dss_{dead.tag}_")]
+    assert len(mine()) == 2
+    dead.abort()
+    assert not mine()
+    # ... and a worker drops its mapping of a ring slot's OLD block when the slot comes back at another size
+    from dss_amd import pthfast
+    a, b, c = (f"/dev/shm/dss_{os.getpid()}_t_s0_{n}" for n in (4096, 8192, 4096))
+    other = f"/dev/shm/dss_{os.getpid()}_t_s1_4096"
+    try:
+        for path, n in ((a, 4096), (b, 8192), (other, 4096)):
+            with open(path, "wb") as f:
+                f.truncate(n)
+        pthfast._block(a, 4096), pthfast._block(other, 4096)
+        assert a in pthfast._BLOCKS
+        pthfast._block(b, 8192)
+        assert a not in pthfast._BLOCKS and b in pthfast._BLOCKS and other in pthfast._BLOCKS
+    finally:
+        for path in (a, b, other):
+            pthfast._BLOCKS.pop(path, None)
+            if os.path.exists(path):
+                os.unlink(path)
+
+
+def test_bucket_batch_is_per_shape_and_inside_the_kernels_row_limits():
+    """extract_features sizes every SHAPE BUCKET on its own shape (the first image's size used to set the batch of every
+    bucket) and never lets a forward's token matrix leave the 32-bit limits of the kernels (M * 4 D bytes, M * T)."""
+    auto = extract.bucket_batch(480, 480, 16, 384, 0, 256, 512)
+    assert auto == 581                                       # four rounds of 2 x 256 workgroups of 256 rows at 901 tokens
+    assert extract.bucket_batch(480, 480, 16, 384, 128, 256, 512) == 128
+    for h, w, p, d in ((32, 32, 16, 384), (48, 640, 8, 768), (640, 640, 8, 768), (2048, 2048, 8, 768), (16, 16, 16, 384)):
+        for want in (0, 1, 10 ** 6):
+            b = extract.bucket_batch(h, w, p, d, want, 256, 512 if d == 384 else 256)
+            t = (h // p) * (w // p) + 1
+            assert b >= 1 and (b == 1 or (b * t * 4 * d < 2 ** 32 and b * t * t < 2 ** 32)), (h, w, p, d, want, b)
+    assert extract.bucket_batch(32, 32, 16, 384, 0, 256, 512) > auto > extract.bucket_batch(960, 960, 16, 384, 0, 256, 512)
 
 
 def test_torch_free_writer_matches_torch_save_for_both_schemas(tmp_path):
