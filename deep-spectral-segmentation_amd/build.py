@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libdss_hip.so"
-SOURCES = ["lib.hip", "preprocess.hip", "layernorm.hip", "attention.hip", "linear384.hip", "affinity.hip", "eigs.hip", "segment.hip"]
+SOURCES = ["lib.hip", "preprocess.hip", "layernorm.hip", "attention.hip", "linear384.hip", "affinity.hip", "eigs.hip", "segment.hip", "gemm.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: the softmax max-chains read MFMA results; in IEEE mode hipcc quiets every such value with an extra
@@ -67,7 +67,11 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    # gemm.hip calls hipBLASLt (the Linear layers that are not hand-written kernels, with an algorithm chosen here); under PyTorch
+    # the soname resolves to the copy torch has already loaded, stand-alone to /opt/rocm's
+    rocm_lib = str(Path(hipcc).resolve().parent.parent / "lib")
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-L" + rocm_lib, "-lhipblaslt",
+           "-Wl,-rpath," + rocm_lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -33,6 +33,10 @@ SYMBOLS = {
     "dss_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dss_linear_k384": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dss_linear_k768": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dss_linear_lt_workspace_bytes": (c_size_t, []),
+    "dss_linear_lt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                              c_void_p]),
+    "dss_linear_lt_describe": (c_int, [ctypes.c_long, c_int, c_int, c_int, c_int, c_int, c_size_t, c_char_p, c_size_t]),
     "dss_lnlinear_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
     "dss_lnlinear_k384": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -256,6 +260,48 @@ def linear_kres(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu:
                                               m, n, int(gelu), PLANAR64 if planar else ROW_MAJOR, dtype_code(x.dtype),
                                               _stream()), entry)
     return out
+
+
+_LT_WORKSPACE: dict = {}     # device index -> the workspace of dss_linear_lt (calls on one stream share it)
+
+
+def _lt_workspace(device: torch.device) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _LT_WORKSPACE:
+        _LT_WORKSPACE[idx] = torch.empty(int(load_library().dss_linear_lt_workspace_bytes()), dtype=torch.uint8, device=device)
+    return _LT_WORKSPACE[idx]
+
+
+def linear_lt(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+              what: str = "") -> torch.Tensor:
+    """``x [..., K] @ weight[N, K]^T (+ bias)`` for the Linear layers that are not hand-written kernels (fc2; at D = 768 also proj and
+    the patch-8 embedding): a hipBLASLt GEMM whose algorithm ``libdss_hip.so`` chooses - never a Stream-K solution (round 6: the
+    library's own first choice at the N = 768 shapes is not reproducible; ``dss_linear_lt`` in include/dss_hip.h).  f16 / bf16
+    operands, fp32 accumulation; ``out_dtype``: the operand type (default) or ``torch.float32``."""
+    k = x.shape[-1]
+    n = weight.shape[0]
+    assert weight.shape[1] == k and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
+    assert bias is None or (bias.dtype == x.dtype and tuple(bias.shape) == (n,))
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    m = x.numel() // k
+    out = torch.empty((*x.shape[:-1], n), dtype=out_dtype, device=x.device)
+    ws = _lt_workspace(x.device)
+    with _timed("library_gemm", m=m, n=n, k=k, what=what):
+        _check(load_library().dss_linear_lt(_dev(x, "x"), _dev(weight, "weight"), 0 if bias is None else _dev(bias, "bias"),
+                                            _dev(out, "out"), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), ws.data_ptr(),
+                                            ws.numel(), _stream()), "dss_linear_lt")
+    return out
+
+
+def linear_lt_describe(m: int, n: int, k: int, dtype: torch.dtype = torch.float16, out_dtype: Optional[torch.dtype] = None,
+                       bias: bool = True) -> str:
+    """hipBLASLt's candidate list for one GEMM problem as ``dss_linear_lt`` walks it: one line per candidate, '*' = the one taken,
+    'x' = passed over (Stream-K, atomic split-K, or workspace)."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib = load_library()
+    _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias),
+                                      int(lib.dss_linear_lt_workspace_bytes()), buf, len(buf)), "dss_linear_lt_describe")
+    return buf.value.decode(errors="replace")
 
 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)

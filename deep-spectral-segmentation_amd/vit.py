@@ -85,7 +85,7 @@ class DinoViT:
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "erf_f16",
                  linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True,
-                 fuse_qkv768: bool = True):
+                 fuse_qkv768: bool = True, library_gemm: str = "lt"):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -126,6 +126,13 @@ class DinoViT:
         # 888-932 TF/s) but the pair also moves the normalised activations through HBM twice: end to end at C3 the two are equal
         # within the box noise (822 -> 828 and 840 -> 844 images/s, same box each), and no standalone LayerNorm launch is left
         self.fuse_qkv768 = bool(fuse_qkv768)
+        # library_gemm: who issues the Linear layers that are not hand-written kernels.  "lt" (default, round 6): dss_linear_lt - hipBLASLt
+        # with an algorithm chosen by libdss_hip.so, never a Stream-K solution (hipBLASLt's own first choice at the N = 768 shapes of
+        # the D = 768 models is one, and it is not reproducible: profiles/r06_forward_stress.txt).  "torch": F.linear, PyTorch's
+        # TunableOp table / hipBLASLt's first heuristic choice - rounds 1-5, kept as the A/B arm
+        if library_gemm not in ("lt", "torch"):
+            raise ValueError("library_gemm must be 'lt' (dss_linear_lt: deterministic hipBLASLt algorithm) or 'torch' (F.linear)")
+        self.library_gemm = library_gemm
         d = self.embed_dim
         sd = state_dict
         need = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
@@ -187,13 +194,25 @@ class DinoViT:
             raise ValueError("gemm_tuning must be 'table' (shipped TunableOp table), 'online' (also tune new shapes) or 'off'")
         setup_gemm_tuning(tune_new_shapes=gemm_tuning == "online", use_table=gemm_tuning != "off")
 
+    def _linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], what: str, out_dtype=None) -> torch.Tensor:
+        """A Linear layer that is not a hand-written kernel (see `library_gemm`)."""
+        if self.library_gemm == "lt":
+            return hip.linear_lt(x, w, b, out_dtype=out_dtype, what=what)
+        k = x.shape[-1]
+        with hip._timed("library_gemm", m=x.numel() // k, n=w.shape[0], k=k, what=what):
+            if out_dtype is not None and out_dtype != x.dtype:
+                out = torch.mm(x.reshape(-1, k), w.t(), out_dtype=out_dtype).view(*x.shape[:-1], w.shape[0])
+                return out if b is None else out + b.to(out_dtype)
+            return F.linear(x, w, b)
+
     def paths(self) -> Dict[str, str]:
         """Which implementation each layer of a block takes in THIS model (what bench.py reports as `vit_paths`: the
         constructor's switches only apply where a kernel exists for the width / patch size / dtype)."""
         blk, d = self.blocks[0], self.embed_dim
         k384 = bool(self.linear_k384) and d == 384
         kres_fc1 = self.gelu in ("erf", "erf_f16") and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
-        lib = "library GEMM (hipBLASLt)"
+        lib = ("library GEMM (hipBLASLt through dss_linear_lt: data-parallel algorithm)" if self.library_gemm == "lt"
+               else "library GEMM (hipBLASLt through F.linear: the library's first choice)")
         return {
             "patch_embed": "dss_patch_embed_p16 (transform + GEMM + position rows, one kernel)" if self.pe16 is not None
                            else f"dss_preprocess_patchify + {lib} + add",
@@ -239,8 +258,7 @@ class DinoViT:
             hip.patch_embed16(img_u8.contiguous(), self.pe16[0], None, self._pos_cache[key], x)
         else:
             patches = hip.preprocess_patchify(img_u8.contiguous(), p, self.dtype)  # [B, N, 3PP]
-            with hip._timed("library_gemm", m=b * hp * wp, n=d, k=patches.shape[-1], what="patch_embed"):
-                tok = F.linear(patches, self.pe_w, self.pe_b)  # [B, N, D]
+            tok = self._linear(patches, self.pe_w, self.pe_b, "patch_embed")  # [B, N, D]
             torch.add(tok, pos, out=x[:, 1:])
 
         pending = None  # branch output not yet added to the residual stream (fused into the next LN)
@@ -262,14 +280,12 @@ class DinoViT:
                 if k384:
                     qkv = hip.linear_kres(hcur, blk["qkv_w"], blk["qkv_b"], planar=True)
                 else:
-                    with hip._timed("library_gemm", m=b * t, n=3 * d, k=d, what="qkv"):
-                        qkv = F.linear(hcur, blk["qkv_w"], blk["qkv_b"])
+                    qkv = self._linear(hcur, blk["qkv_w"], blk["qkv_b"], "qkv")
             o = hip.attention(qkv, heads, self.scale, planar_bt=(b, t)) if qkv_planar else hip.attention(qkv, heads, self.scale)
             if k384:
                 pending = hip.linear_kres(o, blk["proj_w"], blk["proj_b"], planar=True)    # [D/64, B*T, 64]
             else:
-                with hip._timed("library_gemm", m=b * t, n=d, k=d, what="proj"):
-                    pending = F.linear(o, blk["proj_w"], blk["proj_b"])
+                pending = self._linear(o, blk["proj_w"], blk["proj_b"], "proj")
             if kres_fc1 and "fc1_wg" in blk:   # x += pending; LN2; fc1; GELU - one kernel (row-major out: fc2 is a library GEMM)
                 f1 = hip.lnlinear(x, pending, blk["fc1_wg"], blk["fc1_aux"], LN_EPS, gelu=self._gelu_code, residual_planar=bool(k384))
             else:
@@ -278,12 +294,11 @@ class DinoViT:
                 if kres_fc1:
                     f1 = hip.linear_kres(hcur, blk["fc1_w"], blk["fc1_b"], gelu=self._gelu_code)
                 elif self.gelu in ("erf", "erf_f16"):
-                    f1 = F.gelu(F.linear(hcur, blk["fc1_w"], blk["fc1_b"]))
+                    f1 = F.gelu(self._linear(hcur, blk["fc1_w"], blk["fc1_b"], "fc1"))
                 else:
                     f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),
                                                  use_gelu=True).view(b, t, -1)
-            with hip._timed("library_gemm", m=b * t, n=d, k=f1.shape[-1], what="fc2"):
-                pending = F.linear(f1, blk["fc2_w"], blk["fc2_b"])
+            pending = self._linear(f1, blk["fc2_w"], blk["fc2_b"], "fc2")
         return x, pending
 
     @torch.no_grad()
@@ -335,8 +350,7 @@ class DinoViT:
             return res if _finalize else res[0]
         else:  # half operands like every other layer, fp32 accumulate AND fp32 output (no rounding of the features)
             hk = hip.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, self.dtype, residual=pending)
-            with hip._timed("library_gemm", m=b * t, n=d, k=d, what="k_proj"):
-                k = torch.mm(hk.view(b * t, d), blk["k_w"].t(), out_dtype=torch.float32).view(b, t, d)
+            k = self._linear(hk, blk["k_w"], None, "k_proj", out_dtype=torch.float32)
             if _finalize and n > 0:
                 return hip.kfeatures_finalize(k, blk["k_b32"], out=_out)
             k += blk["k_b32"]

@@ -25,12 +25,13 @@
 extern "C" {
 #endif
 
-/* 8: the packed storage of W gained the EDGE STRIP (below, at dss_affinity): a caller that only passes W from dss_affinity* to
+/* 9: + dss_linear_lt / _workspace_bytes / _describe (round 6: the library GEMMs behind this ABI, never a Stream-K algorithm);
+ * 8: the packed storage of W gained the EDGE STRIP (below, at dss_affinity): a caller that only passes W from dss_affinity* to
  * dss_*_eigs* - every caller there is - is unaffected; one that builds or reads packed W itself must follow the layout of the
  * library it runs against (dss_affinity_elems(N) tells them apart: 106 * 4096 at N = 900 with the strip, 120 * 4096 without);
  * 7: + dss_lnlinear_kfeatures (D = 384 / 768, f16 / bf16 operands; round 5);  6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
  * only ever added: a caller built against version n runs against any library with dss_abi_version() >= n. */
-#define DSS_ABI_VERSION 8
+#define DSS_ABI_VERSION 9
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -101,6 +102,25 @@ int dss_linear_k384(const void* A, const void* W, const void* bias, void* C, int
                     int dtype, void* stream);
 int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int M, int N, int gelu, int out_layout,
                     int dtype, void* stream);
+
+/* ---- a6: the Linear layers that are not hand-written kernels (mlp.fc2; at D = 768 also attn.proj and, at patch size 8, the
+ * patch embedding) - torch.nn.Linear inside DINO's Block / PatchEmbed (reached from extract/extract.py:94):
+ *     C[M, N] = A[M, K] . W[N, K]^T + bias[N]        (bias may be NULL)
+ * as a hipBLASLt GEMM whose algorithm THIS library chooses (gemm.hip; round 6): the candidates of hipblasLtMatmulAlgoGetHeuristic
+ * in the library's own order, the first that is neither a Stream-K solution nor a split-K one with atomic accumulation - a
+ * data-parallel kernel, every output tile written by one workgroup, the same bits on every launch.  (hipBLASLt's first choice at
+ * the N = 768 shapes of dino_vitb8 is a Stream-K kernel that is not reproducible on this stack: ~1 launch in 40 000 returns
+ * different values in whole 256-row tiles; profiles/r06_forward_stress.txt.)  A, W, bias in `dtype` (DSS_F16 / DSS_BF16), row-major;
+ * C in `out_dtype` = `dtype` or DSS_F32 (the K projection keeps its fp32 accumulators); fp32 accumulation.  `workspace`: at least
+ * dss_linear_lt_workspace_bytes() bytes the caller owns (may be shared by calls on one stream).  The choice is cached per
+ * (M, N, K, dtypes, bias): the one hipblasLt handle and that cache are the library's only persistent state (mutex-guarded).
+ * dss_linear_lt_describe writes the candidate list for a problem into buf, one line per candidate ('*' = the one taken,
+ * 'x' = passed over: Stream-K / atomic split-K / workspace too small). */
+size_t dss_linear_lt_workspace_bytes(void);
+int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype, int out_dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_dtype, int has_bias, size_t workspace_bytes, char* buf,
+                           size_t buflen);
 
 /* ---- a6 + a6': residual add + LayerNorm + Linear in ONE kernel (DINO Block: `x = x + branch; h = norm(x); y = lin(h)`,
  * i.e. norm1 -> attn.qkv and norm2 -> mlp.fc1 (+ GELU); SURVEY.md Appendix A, reached from extract/extract.py:94).

@@ -19,6 +19,6 @@ if [ -n "${LAB_SED:-}" ]; then sed -e "$LAB_SED" $PATHSRC > scripts/lablib/src_$
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA "$@" -c $PATHSRC -o scripts/lablib/${REPL}_$TAG.o
 rm -f scripts/lablib/src_$TAG.hip
 OBJS=$(ls $PKG/lib/obj/*.o | grep -v "/${REPL}.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/lablib/libdss_hip_$TAG.so $OBJS scripts/lablib/${REPL}_$TAG.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/lablib/libdss_hip_$TAG.so $OBJS scripts/lablib/${REPL}_$TAG.o -L/opt/rocm/lib -lhipblaslt -Wl,-rpath,/opt/rocm/lib
 rm -f scripts/lablib/${REPL}_$TAG.o
 echo "scripts/lablib/libdss_hip_$TAG.so"

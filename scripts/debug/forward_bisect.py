@@ -25,7 +25,7 @@ arm = sys.argv[5] if len(sys.argv) > 5 else "plain"
 opts = {}
 for kv in (sys.argv[6].split(",") if len(sys.argv) > 6 and sys.argv[6] else []):
     k_, v_ = kv.split("=")
-    opts[k_] = v_ if k_ in ("gelu", "gemm_tuning") else (int(v_) if k_ == "linear_kres" else bool(int(v_)))
+    opts[k_] = v_ if k_ in ("gelu", "gemm_tuning", "library_gemm") else (int(v_) if k_ == "linear_kres" else bool(int(v_)))
 if arm == "rocblas":
     torch.backends.cuda.preferred_blas_library("cublas")
 dev = torch.device("cuda")
