@@ -46,6 +46,9 @@ __device__ unsigned long long dss_clock_buf[4];
 #define DSS_CLOCK_END
 #endif
 
+#ifndef DSS_ATTN_PRIO
+#define DSS_ATTN_PRIO 0       // lab switch (round 6): bit 0 = s_setprio 1 over the score MFMAs, bit 1 = over the P.V MFMAs
+#endif
 #ifndef DSS_ATTN_PIPE
 #define DSS_ATTN_PIPE 0       // lab switch (round 6): 1 = attn_fwd_pipe_kernel (next block's score tile in front of this block's softmax)
 #endif
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
     };
     constexpr bool F16SUM = DSS_ATTN_F16SUM && std::is_same<T, f16>::value;
     if (!exact) {
+      if (DSS_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
       s = scores(false);
+      if (DSS_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
       if constexpr (F16SUM) {
         if (tail) { acc = exp_rowsum(s); pack(); }
         else acc = exp_pack_rowsum_f16(s, pb0, pb1);
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
     }
     l += acc;
     if constexpr (!F16SUM) pack();
+    if (DSS_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
     {
       const V8 v0 = lds_read_tr_pair<T>((lds_t_t)(size_t)(vptr[0] + VOFF),
                                         (lds_t_t)(size_t)(vptr[0] + VOFF + 1024));
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
       o0 = mfma32x32x16(v0, pb1, o0);
       o1 = mfma32x32x16(v1, pb1, o1);
     }
+    if (DSS_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };
 
   auto stage_sync = [&]() {

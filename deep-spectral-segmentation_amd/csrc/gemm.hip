@@ -59,9 +59,12 @@ int name_field(const std::string& name, const char* key) {
   return -1;
 }
 
-// a solution whose result does not depend on the order in which workgroups finish
+// a solution whose result does not depend on the order in which workgroups finish.  TWO guards: the heuristic is asked with a
+// workspace budget of ZERO - a Stream-K solution needs one for its partial tiles and flags, a multi-buffer split-K one for its
+// buffers, so the library itself leaves them out -, and whatever name the library gives for a candidate is checked on top
+// (a build that gives no names is covered by the first guard alone)
 bool deterministic_solution(const std::string& name) {
-  if (name.empty()) return false;                                   // unknown kernel: not taken
+  if (name.empty()) return true;                                    // no name from this build: the zero-workspace rule stands alone
   if (name_field(name, "SK") > 0) return false;                     // Stream-K
   if (name_field(name, "GSU") > 1 && name.find("GSUAMB") == std::string::npos) return false;   // split-K into one buffer
   return true;
@@ -112,11 +115,10 @@ int ensure_handle() {
 }
 
 // walks the heuristic's candidates; `log` (optional) receives one line per candidate
-int choose(LtProblem& p, size_t workspace_bytes, LtChoice& out, std::string* log) {
+int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // budget: 0 (see deterministic_solution) except for describe's second listing
   hipblasLtMatmulPreference_t pref = nullptr;
   DSS_LT(hipblasLtMatmulPreferenceCreate(&pref));
-  hipblasStatus_t st = hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &workspace_bytes,
-                                                             sizeof(workspace_bytes));
+  hipblasStatus_t st = hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &budget, sizeof(budget));
   constexpr int WANT = 32;
   std::vector<hipblasLtMatmulHeuristicResult_t> res(WANT);
   int got = 0;
@@ -127,14 +129,16 @@ int choose(LtProblem& p, size_t workspace_bytes, LtChoice& out, std::string* log
   bool found = false;
   int rejected = 0;
   for (int i = 0; i < got; ++i) {
-    if (res[i].state != HIPBLAS_STATUS_SUCCESS) continue;
-    const std::string name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, res[i].algo);
-    const bool ok = deterministic_solution(name) && res[i].workspaceSize <= workspace_bytes;
+    // the solution name carries every Tensile parameter (`_SK3_`, `_GSU2_`, ...); the kernel name is the fallback where a build of
+    // the library does not give one
+    std::string name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, res[i].algo);
+    if (name.empty()) name = hipblaslt_ext::getKernelNameFromAlgo(g_handle, res[i].algo);
+    const bool ok = res[i].state == HIPBLAS_STATUS_SUCCESS && deterministic_solution(name) && res[i].workspaceSize <= budget;
     if (log) {
-      char head[96];
-      snprintf(head, sizeof(head), "%s#%d ws=%zu idx=%d ", (ok && !found) ? "* " : (ok ? "  " : "x "), i, res[i].workspaceSize,
-               hipblaslt_ext::getIndexFromAlgo(res[i].algo));
-      *log += head + name + "\n";
+      char head[112];
+      snprintf(head, sizeof(head), "%s#%d state=%d ws=%zu idx=%d ", (ok && !found) ? "* " : (ok ? "  " : "x "), i, (int)res[i].state,
+               res[i].workspaceSize, hipblaslt_ext::getIndexFromAlgo(res[i].algo));
+      *log += head + (name.empty() ? std::string("<no name>") : name) + "\n";
     }
     if (ok && !found) {
       out.algo = res[i].algo;
@@ -147,15 +151,17 @@ int choose(LtProblem& p, size_t workspace_bytes, LtChoice& out, std::string* log
     }
     if (!ok) ++rejected;
   }
-  if (!found)
+  if (!found) {
+    if (log) { *log += "(no candidate taken)\n"; return DSS_OK; }      // dss_linear_lt_describe reports, dss_linear_lt fails
     return fail(DSS_ERR_HIP, "dss_linear_lt: none of hipBLASLt's %d candidates is a data-parallel (non-Stream-K) solution", got);
+  }
   return DSS_OK;
 }
 
 }  // namespace
 }  // namespace dss
 
-extern "C" size_t dss_linear_lt_workspace_bytes(void) { return (size_t)32 << 20; }
+extern "C" size_t dss_linear_lt_workspace_bytes(void) { return 0; }   // the algorithm is chosen among those that need none
 
 extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
                              int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
@@ -171,14 +177,14 @@ extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, voi
   if (int rc = build_problem(p, M, N, K, dtype, out_dtype, bias)) return rc;
   const auto key = std::make_tuple(M, N, K, dtype, out_dtype, bias ? 1 : 0);
   auto it = g_cache.find(key);
-  if (it == g_cache.end() || it->second.workspace > workspace_bytes) {
+  if (it == g_cache.end()) {
     LtChoice c;
-    if (int rc = choose(p, workspace_bytes, c, nullptr)) return rc;
+    if (int rc = choose(p, 0, c, nullptr)) return rc;
     it = g_cache.insert_or_assign(key, c).first;
   }
   const float alpha = 1.0f, beta = 0.0f;
   DSS_LT(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &it->second.algo, workspace,
-                         workspace_bytes, (hipStream_t)stream));
+                         it->second.workspace, (hipStream_t)stream));
   return DSS_OK;
 }
 
@@ -195,7 +201,20 @@ extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_d
   if (int rc = build_problem(p, M, N, K, dtype, out_dtype, has_bias ? (const void*)&dummy : nullptr)) return rc;
   LtChoice c;
   std::string log;
-  if (int rc = choose(p, workspace_bytes, c, &log)) return rc;
+  if (int rc = choose(p, 0, c, &log)) return rc;
+  if (workspace_bytes > 0) {      // for the record: what a caller that offers a workspace (PyTorch's route) is offered first
+    std::string other;
+    LtChoice c2;
+    if (choose(p, workspace_bytes, c2, &other) == DSS_OK) {
+      log += "-- with a workspace budget of " + std::to_string(workspace_bytes) + " bytes the list would start:\n";
+      size_t pos = 0;
+      for (int i = 0; i < 4 && pos != std::string::npos; ++i) {
+        const size_t e = other.find('\n', pos);
+        log += "   " + other.substr(pos, e == std::string::npos ? std::string::npos : e - pos + 1);
+        pos = e == std::string::npos ? e : e + 1;
+      }
+    }
+  }
   snprintf(buf, buflen, "%s", log.c_str());
   return DSS_OK;
 }

@@ -268,7 +268,7 @@ _LT_WORKSPACE: dict = {}     # device index -> the workspace of dss_linear_lt (c
 def _lt_workspace(device: torch.device) -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _LT_WORKSPACE:
-        _LT_WORKSPACE[idx] = torch.empty(int(load_library().dss_linear_lt_workspace_bytes()), dtype=torch.uint8, device=device)
+        _LT_WORKSPACE[idx] = torch.empty(max(16, int(load_library().dss_linear_lt_workspace_bytes())), dtype=torch.uint8, device=device)
     return _LT_WORKSPACE[idx]
 
 
@@ -299,8 +299,8 @@ def linear_lt_describe(m: int, n: int, k: int, dtype: torch.dtype = torch.float1
     'x' = passed over (Stream-K, atomic split-K, or workspace)."""
     buf = ctypes.create_string_buffer(1 << 16)
     lib = load_library()
-    _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias),
-                                      int(lib.dss_linear_lt_workspace_bytes()), buf, len(buf)), "dss_linear_lt_describe")
+    _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias), 32 << 20, buf, len(buf)),
+           "dss_linear_lt_describe")
     return buf.value.decode(errors="replace")
 
 

@@ -16,7 +16,10 @@ for p in os.environ.get("DSS_LAB_LIBRARY", "").split(":"):
         libs[os.path.basename(p).replace("libdss_hip_", "").replace(".so", "")] = hip.load_library(p)
 torch.manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
-for (b, n, d, k) in [(2036, 900, 384, 5), (4072, 900, 384, 5), (256, 3600, 768, 15), (2036, 196, 384, 5)]:
+cases = [(2036, 900, 384, 5), (4072, 900, 384, 5), (256, 3600, 768, 15), (2036, 196, 384, 5)]
+if os.environ.get("EIGS_AB_CASES"):        # "B,N,D,K;B,N,D,K;..."
+    cases = [tuple(int(v) for v in c.split(",")) for c in os.environ["EIGS_AB_CASES"].split(";") if c]
+for (b, n, d, k) in cases:
     side = int(n ** 0.5)
     base = torch.randn(b, n, d, device="cuda")
     yy, xx = torch.meshgrid(torch.arange(side, device="cuda"), torch.arange(side, device="cuda"), indexing="ij")
