@@ -59,12 +59,13 @@ int name_field(const std::string& name, const char* key) {
   return -1;
 }
 
-// a solution whose result does not depend on the order in which workgroups finish.  TWO guards: the heuristic is asked with a
-// workspace budget of ZERO - a Stream-K solution needs one for its partial tiles and flags, a multi-buffer split-K one for its
-// buffers, so the library itself leaves them out -, and whatever name the library gives for a candidate is checked on top
-// (a build that gives no names is covered by the first guard alone)
+// a solution whose result does not depend on the order in which workgroups finish, judged by the Tensile parameters its name
+// spells out (what this stack's names look like - profiles/r06_lt_describe.txt: the Stream-K one is
+// `Custom_Cijk_..._NTD_SK3_UserArgs_MT256x256x64_..._shortname0_gfx950`, the data-parallel ones carry `_GSU0_GSUAMB_` and no SK
+// field).  A candidate without a name is NOT taken: better to fail loudly on a build of hipBLASLt that gives none than to guess.
+// (A zero workspace budget does not work as the guard: on this stack nearly every data-parallel candidate reports a workspace too.)
 bool deterministic_solution(const std::string& name) {
-  if (name.empty()) return true;                                    // no name from this build: the zero-workspace rule stands alone
+  if (name.empty()) return false;
   if (name_field(name, "SK") > 0) return false;                     // Stream-K
   if (name_field(name, "GSU") > 1 && name.find("GSUAMB") == std::string::npos) return false;   // split-K into one buffer
   return true;
@@ -115,7 +116,7 @@ int ensure_handle() {
 }
 
 // walks the heuristic's candidates; `log` (optional) receives one line per candidate
-int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // budget: 0 (see deterministic_solution) except for describe's second listing
+int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // budget: the caller's workspace
   hipblasLtMatmulPreference_t pref = nullptr;
   DSS_LT(hipblasLtMatmulPreferenceCreate(&pref));
   hipblasStatus_t st = hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &budget, sizeof(budget));
@@ -161,7 +162,7 @@ int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // 
 }  // namespace
 }  // namespace dss
 
-extern "C" size_t dss_linear_lt_workspace_bytes(void) { return 0; }   // the algorithm is chosen among those that need none
+extern "C" size_t dss_linear_lt_workspace_bytes(void) { return (size_t)128 << 20; }   // (the candidates of this stack ask for up to 64 MiB)
 
 extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
                              int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
@@ -177,9 +178,9 @@ extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, voi
   if (int rc = build_problem(p, M, N, K, dtype, out_dtype, bias)) return rc;
   const auto key = std::make_tuple(M, N, K, dtype, out_dtype, bias ? 1 : 0);
   auto it = g_cache.find(key);
-  if (it == g_cache.end()) {
+  if (it == g_cache.end() || it->second.workspace > workspace_bytes) {
     LtChoice c;
-    if (int rc = choose(p, 0, c, nullptr)) return rc;
+    if (int rc = choose(p, workspace_bytes, c, nullptr)) return rc;
     it = g_cache.insert_or_assign(key, c).first;
   }
   const float alpha = 1.0f, beta = 0.0f;
@@ -201,20 +202,7 @@ extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_d
   if (int rc = build_problem(p, M, N, K, dtype, out_dtype, has_bias ? (const void*)&dummy : nullptr)) return rc;
   LtChoice c;
   std::string log;
-  if (int rc = choose(p, 0, c, &log)) return rc;
-  if (workspace_bytes > 0) {      // for the record: what a caller that offers a workspace (PyTorch's route) is offered first
-    std::string other;
-    LtChoice c2;
-    if (choose(p, workspace_bytes, c2, &other) == DSS_OK) {
-      log += "-- with a workspace budget of " + std::to_string(workspace_bytes) + " bytes the list would start:\n";
-      size_t pos = 0;
-      for (int i = 0; i < 4 && pos != std::string::npos; ++i) {
-        const size_t e = other.find('\n', pos);
-        log += "   " + other.substr(pos, e == std::string::npos ? std::string::npos : e - pos + 1);
-        pos = e == std::string::npos ? e : e + 1;
-      }
-    }
-  }
+  if (int rc = choose(p, workspace_bytes, c, &log)) return rc;
   snprintf(buf, buflen, "%s", log.c_str());
   return DSS_OK;
 }

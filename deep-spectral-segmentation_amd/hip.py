@@ -299,8 +299,8 @@ def linear_lt_describe(m: int, n: int, k: int, dtype: torch.dtype = torch.float1
     'x' = passed over (Stream-K, atomic split-K, or workspace)."""
     buf = ctypes.create_string_buffer(1 << 16)
     lib = load_library()
-    _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias), 32 << 20, buf, len(buf)),
-           "dss_linear_lt_describe")
+    _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias),
+                                      int(lib.dss_linear_lt_workspace_bytes()), buf, len(buf)), "dss_linear_lt_describe")
     return buf.value.decode(errors="replace")
 
 

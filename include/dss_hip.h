@@ -112,13 +112,12 @@ int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int
  * the N = 768 shapes of dino_vitb8 is a Stream-K kernel that is not reproducible on this stack: ~1 launch in 40 000 returns
  * different values in whole 256-row tiles; profiles/r06_forward_stress.txt.)  A, W, bias in `dtype` (DSS_F16 / DSS_BF16), row-major;
  * C in `out_dtype` = `dtype` or DSS_F32 (the K projection keeps its fp32 accumulators); fp32 accumulation.  `workspace`: at least
- * dss_linear_lt_workspace_bytes() bytes the caller owns (may be shared by calls on one stream; today 0 - the heuristic is asked
- * with a zero workspace budget, which is what keeps Stream-K and multi-buffer split-K solutions out of its list in the first
- * place; the names of the candidates are checked on top).  The choice is cached per
+ * dss_linear_lt_workspace_bytes() bytes the caller owns (128 MiB; may be shared by calls on one stream: nearly every
+ * data-parallel candidate of this stack reports a workspace of 30-64 MiB).  A candidate is judged by the Tensile parameters in its
+ * solution name (`_SK<n>_`, `_GSU<n>_`); one without a name is never taken.  The choice is cached per
  * (M, N, K, dtypes, bias): the one hipblasLt handle and that cache are the library's only persistent state (mutex-guarded).
  * dss_linear_lt_describe writes the candidate list for a problem into buf, one line per candidate ('*' = the one taken,
- * 'x' = passed over), followed - when workspace_bytes > 0 - by the first four candidates a caller offering that much workspace
- * (PyTorch's route) would be given. */
+ * 'x' = passed over: Stream-K, atomic split-K, no name, or a workspace beyond workspace_bytes). */
 size_t dss_linear_lt_workspace_bytes(void);
 int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);

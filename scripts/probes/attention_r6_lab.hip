@@ -46,6 +46,16 @@ __device__ unsigned long long dss_clock_buf[4];
 #define DSS_CLOCK_END
 #endif
 
+#ifndef DSS_ATTN_PRIO
+#define DSS_ATTN_PRIO 0       // lab switch (round 6): bit 0 = s_setprio 1 over the score MFMAs, bit 1 = over the P.V MFMAs
+#endif
+#ifndef DSS_ATTN_PIPE
+#define DSS_ATTN_PIPE 0       // lab switch (round 6): 1 = attn_fwd_pipe_kernel (next block's score tile in front of this block's softmax)
+#endif
+#ifndef DSS_ATTN_F16SUM
+#define DSS_ATTN_F16SUM 0     // lab switch (round 6): 1 = row sums of the rounded probabilities on v_pk_add_f16 (f16 operands)
+#endif
+
 namespace dss {
 
 static constexpr int DH = 64;  // head dim of every DINO ViT
@@ -406,9 +416,11 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
         pb1[e] = from_f32<T>(s[8 + e]);
       }
     };
-    constexpr bool F16SUM = std::is_same<T, f16>::value;   // f16 operands: row sums of the rounded probabilities (exp_pack_rowsum_f16)
+    constexpr bool F16SUM = DSS_ATTN_F16SUM && std::is_same<T, f16>::value;
     if (!exact) {
+      if (DSS_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
       s = scores(false);
+      if (DSS_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
       if constexpr (F16SUM) {
         if (tail) { acc = exp_rowsum(s); pack(); }
         else acc = exp_pack_rowsum_f16(s, pb0, pb1);
@@ -449,13 +461,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
     }
     l += acc;
     if constexpr (!F16SUM) pack();
-    // Round 6: the wave runs at priority 1 from its V-fragment reads to its last P.V MFMA.  The SIMD arbitrates VALU issue by
-    // priority, then age: at equal priority an OLDER wave's softmax (36 VALU instructions) goes in front of a younger wave's
-    // ready MFMAs and the matrix pipe idles beside a busy VALU port (counters: pipe 47 % busy, VALU port 64 %, both at once 21 %
-    // of the cycles; profiles/r06_attention_lab.txt); with the P.V block raised, those four MFMAs go out as soon as their
-    // operands are there and the others' softmax fills the 28 free issue cycles behind each.  Measured (same process, alternating):
-    // -0.7 % at T = 901, -1.4 % at T = 3601 on top of the f16 row sums; raising the score MFMAs as well (or instead) is slower.
-    __builtin_amdgcn_s_setprio(1);
+    if (DSS_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
     {
       const V8 v0 = lds_read_tr_pair<T>((lds_t_t)(size_t)(vptr[0] + VOFF),
                                         (lds_t_t)(size_t)(vptr[0] + VOFF + 1024));
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
       o0 = mfma32x32x16(v0, pb1, o0);
       o1 = mfma32x32x16(v1, pb1, o1);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (DSS_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };
 
   auto stage_sync = [&]() {
@@ -538,12 +544,391 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
   }
 }
 
+// ================================================================================================
+// attn_fwd_pipe_kernel (round 6): the same tiles, layouts and arithmetic with the score tile of key block b + 1 issued BEFORE the
+// softmax of block b - two S accumulators in flight per wave: the softmax reads a tile finished one block ago instead of waiting
+// for the MFMA chain that feeds it, and its VALU instructions follow this wave's own score MFMAs in program order.  What
+// changes around that:
+//   * THREE stage buffers (48 KB): block b + 1 may belong to the next stage while block b still reads the V rows of this one.  The
+//     stage barrier sits in front of the first score tile of a stage, the DMA of stage s + 1 goes out right behind the barrier of
+//     stage s (its buffer, stage s - 2's, was last read two steps before every wave reached that barrier) - still one barrier
+//     per 64 keys, and a DMA has two blocks of time to land;
+//   * a block's LDS position (2 x buffer + half) is blk % 6: compile-time in a body of SIX blocks; block 0 (no running maximum yet:
+//     exact path, the next tile issued behind it) is peeled, the last blocks run on runtime offsets;
+//   * a rescale (rare) finds block b + 1's tile already taken against the old running maximum: the tile is shifted by
+//     m_old - m_new (fp32 add; the only place where the result can differ in the last bit from the unpipelined kernel's).
+template <class T, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void attn_fwd_pipe_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+                                                               int heads, int nb, int nqb, float scale_log2, int planar) {
+  typedef typename vec8<T>::type V8;
+  typedef typename vec4<T>::type V4;
+  constexpr int SK = 64;               // keys per stage
+  constexpr int OPB = SK * 128;        // bytes per operand per stage
+  constexpr int NBUF = 3;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF][2][OPB];   // [stage buffer][K | V]
+  // NW = 8 runs at 128 registers per lane, and the two per-lane DMA offsets - used once per stage - are what the register allocator
+  // evicts first: as scratch reloads they would sit on vmcnt between the two DMA instructions of a stage (the V piece waiting for
+  // the K piece to LAND).  They are parked in LDS instead and come back through ds_read_addtid_b32 (M0 base + 4 x lane: no address
+  // register) on lgkmcnt.
+  constexpr bool PARK = NW == 8;
+  __shared__ __attribute__((aligned(256))) unsigned dma_park[PARK ? NW : 1][2][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  int qblk, group;
+  {
+    const int id = blockIdx.x, groups = heads * nb, g8 = groups & ~7;   // XCD-aware order: see attn_fwd_kernel
+    if (id < nqb * g8) {
+      const int xcd = id & 7, slot = id >> 3;
+      group = (slot / nqb) * 8 + xcd;
+      qblk = slot % nqb;
+    } else {
+      const int r = id - nqb * g8;
+      group = g8 + r / nqb;
+      qblk = r % nqb;
+    }
+  }
+  const int head = group % heads, b = group / heads;
+  const long plane = (long)nb * Tn * DH;
+  const long rs = planar ? DH : 3L * heads * DH;
+  const long koff = planar ? heads * plane : (long)heads * DH;
+  const T* base = planar ? qkv + head * plane + (long)b * Tn * DH : qkv + (long)b * Tn * rs + (long)head * DH;
+  static_assert(NW == 8 || NW == 4, "a stage is eight 1 KB pieces per operand, shared evenly by the waves");
+  const int q0 = qblk * (32 * NW) + wave * 32;
+  const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
+
+  // ---- K/V stage DMA (as in attn_fwd_kernel; one K piece + one V piece per wave and stage) ------------------------------
+  const unsigned rb = (unsigned)(rs * 2);
+  auto uniform_ptr = [](const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+  };
+  const unsigned char* ksrc = uniform_ptr(base + koff);
+  const unsigned char* vsrc = uniform_ptr(base + 2 * koff);
+  const unsigned lds0 = (unsigned)(size_t)(lds_as3_t)(&lds[0][0][0]);
+  auto dma16 = [&](const unsigned char* src, unsigned off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(off), "s"(src) : "memory");
+  };
+  // The stage advance rides on the SCALAR source pointers (one s_add per operand and stage); a lane's offset inside a stage is a
+  // constant of the kernel - two VGPRs, no VALU per stage.  Keys past the end of the sequence (the last, ragged stage only): the
+  // row is clamped to the last key's (finite data; their scores are masked), with offsets rebuilt from the lane id on that one
+  // occasion.
+  const unsigned dma_step = (unsigned)SK * rb;
+  const int dma_r = 8 * wave + (lane >> 3);                         // this lane's key row inside a stage
+  const unsigned dma_kc = 16u * (unsigned)((lane & 7) ^ ((dma_r >> 1) & 7));
+  const unsigned dma_vc = 16u * (unsigned)((lane & 7) ^ (((dma_r >> 1) & 1) << 2));
+  const unsigned dma_koff = (unsigned)dma_r * rb + dma_kc, dma_voff = (unsigned)dma_r * rb + dma_vc;
+  const unsigned park0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_as3_t)(&dma_park[PARK ? wave : 0][0][0]));
+  if constexpr (PARK) {
+    dma_park[wave][0][lane] = dma_koff;
+    dma_park[wave][1][lane] = dma_voff;
+  }
+  int dma_stage = 0;                                                // (scalar) the next stage to issue
+  auto issue = [&](int buf, auto parkedc) {                         // the next stage in order, into stage buffer `buf`
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * 2 * OPB + wave * 1024));
+    unsigned ko = dma_koff, vo = dma_voff;
+    // (wave w moves pieces w, w + NW, ..: rows 8 NW apart share their swizzle - (r >> 1) & 7 and (r >> 1) & 1 repeat every 16 rows)
+    if (dma_stage * SK + SK <= Tn) {
+      if constexpr (PARK && decltype(parkedc)::value) {   // (the prologue's two stages go out from the registers)
+        unsigned keep;
+        asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tds_read_addtid_b32 %0 offset:0\n\t"
+                     "ds_read_addtid_b32 %1 offset:256\n\ts_mov_b32 m0, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ko), "=&v"(vo), "=&s"(keep) : "s"(park0) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < 8 / NW; ++j) {
+        dma16(ksrc + (size_t)(8 * NW * j) * rb, ko, dst + (unsigned)(NW * 1024 * j));
+        dma16(vsrc + (size_t)(8 * NW * j) * rb, vo, dst + OPB + (unsigned)(NW * 1024 * j));
+      }
+    } else {                                                        // the ragged last stage
+      unsigned l;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));   // fresh lane id: nothing held for this
+#pragma unroll
+      for (int j = 0; j < 8 / NW; ++j) {
+        const int r = 8 * wave + (int)(l >> 3) + 8 * NW * j;
+        const int rc = min(r, Tn - 1 - dma_stage * SK);
+        const unsigned ro = (unsigned)rc * rb;
+        dma16(ksrc, ro + 16u * ((l & 7u) ^ (unsigned)((r >> 1) & 7)), dst + (unsigned)(NW * 1024 * j));
+        dma16(vsrc, ro + 16u * ((l & 7u) ^ (unsigned)(((r >> 1) & 1) << 2)), dst + OPB + (unsigned)(NW * 1024 * j));
+      }
+    }
+    ksrc += dma_step;
+    vsrc += dma_step;
+    ++dma_stage;
+  };
+  issue(0, std::false_type{});
+
+  V8 qf[4];
+  {
+    int qa = q0 + li;
+    qa = qa < Tn ? qa : Tn - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const V8*>(base + (long)qa * rs + 16 * s + 8 * hh);
+    asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));   // (waited for HERE: see attn_fwd_kernel)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = from_f32<T>(to_f32<T>(qf[s][e]) * scale_log2);
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -1.0e30f;
+  float l = 0.f;
+  f32x16 cm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cm[r] = -m;
+  unsigned kptr[4];
+  {
+    const unsigned xk = (unsigned)(((li >> 1) & 7) << 4);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) kptr[sl] = lds0 + ((unsigned)(li * 128) + (((unsigned)(32 * sl + 16 * hh)) ^ xk));
+  }
+  unsigned vptr[2];
+  {
+    const unsigned tr_row = (unsigned)(4 * hh + ((lane & 15) >> 2));
+    const unsigned b3 = (unsigned)((lane >> 3) & 1);                // bit 1 of the row: the V swizzle flips the 64-byte half
+    const unsigned inrow = (unsigned)(32 * ((lane >> 4) & 1) + 8 * (lane & 3));
+    vptr[0] = lds0 + (tr_row * 128 + 64 * (0 ^ b3) + inrow);
+    vptr[1] = lds0 + (tr_row * 128 + 64 * (1 ^ b3) + inrow);
+  }
+  typedef __attribute__((address_space(3))) const V8* lds_v8_t;
+  typedef __attribute__((address_space(3))) const T* lds_t_t;
+  const float ovf_bar = 64.0f;
+  constexpr bool F16SUM = DSS_ATTN_F16SUM && std::is_same<T, f16>::value;
+  const int nblk = (Tn + 31) / 32, nfullblk = Tn / 32, ns = (Tn + SK - 1) / SK;
+
+  // LDS byte offset of position pos = 2 x buffer + half (K fragments; the V rows of the same keys are OPB further)
+  auto pos_off = [](int pos) { return (pos >> 1) * 2 * OPB + (pos & 1) * 4096; };
+
+  // the score tile of one 32-key block against the running maximum (q.k - m).  posc: std::integral_constant (the offsets fold into
+  // the reads; K fragments as the pinned two-deep pipeline) or a plain int (remainder blocks)
+  auto scores_fast = [&](auto posc, int key0, bool tail) -> f32x16 {
+    f32x16 s;
+    if (tail) {
+      const int KOFF = pos_off((int)posc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn ? cm[r] : -INFINITY;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(*(lds_v8_t)(size_t)(kptr[sl] + KOFF), qf[sl], s);
+      return s;
+    }
+    V8 fa, fb;
+    if constexpr (std::is_same<decltype(posc), int>::value) {
+      const unsigned KOFF = (unsigned)pos_off(posc);
+      kfrag_read<0>(fa, kptr[0] + KOFF); kfrag_read<0>(fb, kptr[1] + KOFF);
+      kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[0], cm);
+      kfrag_read<0>(fa, kptr[2] + KOFF);
+      kfrag_wait<1>(fb); s = mfma32x32x16(fb, qf[1], s);
+      kfrag_read<0>(fb, kptr[3] + KOFF);
+    } else {
+      constexpr int KO = (decltype(posc)::value >> 1) * 2 * OPB + (decltype(posc)::value & 1) * 4096;
+      kfrag_read<KO>(fa, kptr[0]); kfrag_read<KO>(fb, kptr[1]);
+      kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[0], cm);
+      kfrag_read<KO>(fa, kptr[2]);
+      kfrag_wait<1>(fb); s = mfma32x32x16(fb, qf[1], s);
+      kfrag_read<KO>(fb, kptr[3]);
+    }
+    kfrag_wait<1>(fa); s = mfma32x32x16(fa, qf[2], s);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb), "+v"(s));
+    s = mfma32x32x16(fb, qf[3], s);
+    return s;
+  };
+  auto stage_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of the stage have landed
+    __builtin_amdgcn_s_barrier();                                   // ... everyone's; and the buffer two stages back is free
+    asm volatile("" ::: "memory");
+  };
+  // block blk + 1 (position nposc): the stage hand-over if it opens a stage, then its score tile.  (Active waves only: a wave
+  // without queries runs `idle_stages` below - the same barriers and DMA pieces, nothing else - so that no tile assignment in here
+  // is conditional: a conditional one makes the compiler preserve the tile it replaces, 16 moves per block.)
+  auto next_tile = [&](auto nposc, int blk1, bool tail, f32x16& nxt) {
+    // (a compile-time position means the six-block body, where block blk1 is known to exist: no condition on the assignment)
+    if constexpr (std::is_same<decltype(nposc), int>::value) { if (blk1 >= nblk) return; }
+    if (((int)nposc & 1) == 0) {
+      stage_sync();
+      if ((blk1 >> 1) + 1 < ns) issue((((int)nposc >> 1) + 1) % NBUF, std::true_type{});
+    }
+    nxt = scores_fast(nposc, blk1 * 32, tail);
+  };
+  // softmax of block blk (tile `cur`, unless FIRST) into the packed probabilities; the rare rescale also shifts `nxt`
+  auto softmax = [&](auto firstc, int pos, int blk, bool tail, f32x16& cur, f32x16& nxt, V8& pb0, V8& pb1) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    f32x16 s;
+    if constexpr (!FIRST) s = cur;
+    float acc = 0.f;
+    bool exact = FIRST;
+    auto pack = [&]() {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pb0[e] = from_f32<T>(s[e]);
+        pb1[e] = from_f32<T>(s[8 + e]);
+      }
+    };
+    if constexpr (!FIRST) {
+      if constexpr (F16SUM) {
+        if (tail) { acc = exp_rowsum(s); pack(); }
+        else acc = exp_pack_rowsum_f16(s, pb0, pb1);
+      } else {
+        acc = tail ? exp_rowsum(s) : exp_rowsum_ordered(s);
+      }
+      unsigned long long ovf;
+      asm volatile("v_cmp_nle_f32_e64 %0, %1, %2" : "=s"(ovf) : "v"(acc), "s"(ovf_bar));
+      exact = ovf != 0ull;
+    }
+    if (exact) {                           // wave-uniform: block 0, or a row maximum that grew by > 2^6
+      const int KOFF = pos_off(pos), key0 = blk * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = (!tail || (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh) < Tn) ? 0.f : -INFINITY;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) s = mfma32x32x16(*(lds_v8_t)(size_t)(kptr[sl] + KOFF), qf[sl], s);
+      float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])),
+                           fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+      mx = half_pair_max(mx);
+      const float m_new = fmaxf(m, mx);
+      if constexpr (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new), shift = m - m_new;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        if (blk + 1 < nblk) {              // the tile in flight was taken against the old maximum
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nxt[r] += shift;
+        }
+      }
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[r] = -m_new;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_new);
+        a0 += s[r];
+        a1 += s[r + 1];
+      }
+      acc = a0 + a1;
+      if constexpr (F16SUM) pack();
+    }
+    l += acc;
+    if constexpr (!F16SUM) pack();
+  };
+  auto pv = [&](auto cposc, const V8& pb0, const V8& pb1) {
+    unsigned v0a = vptr[0], v1a = vptr[1];
+    if constexpr (std::is_same<decltype(cposc), int>::value) {
+      const unsigned off = (unsigned)(pos_off(cposc) + OPB);
+      v0a += off; v1a += off;
+    }
+    constexpr int VO = std::is_same<decltype(cposc), int>::value ? 0 : (((int)decltype(cposc){} >> 1) * 2 * OPB + ((int)decltype(cposc){} & 1) * 4096 + OPB);
+    {
+      const V8 v0 = lds_read_tr_pair<T>((lds_t_t)(size_t)(v0a + VO), (lds_t_t)(size_t)(v0a + VO + 1024));
+      const V8 v1 = lds_read_tr_pair<T>((lds_t_t)(size_t)(v1a + VO), (lds_t_t)(size_t)(v1a + VO + 1024));
+      o0 = mfma32x32x16(v0, pb0, o0);
+      o1 = mfma32x32x16(v1, pb0, o1);
+    }
+    {
+      const V8 v0 = lds_read_tr_pair<T>((lds_t_t)(size_t)(v0a + VO + 2048), (lds_t_t)(size_t)(v0a + VO + 3072));
+      const V8 v1 = lds_read_tr_pair<T>((lds_t_t)(size_t)(v1a + VO + 2048), (lds_t_t)(size_t)(v1a + VO + 3072));
+      o0 = mfma32x32x16(v0, pb1, o0);
+      o1 = mfma32x32x16(v1, pb1, o1);
+    }
+  };
+  // one step: block blk + 1's tile goes out, block blk is finished behind it
+  auto step = [&](auto cposc, auto nposc, int blk, bool cur_tail, bool nxt_tail, f32x16& cur, f32x16& nxt) {
+    next_tile(nposc, blk + 1, nxt_tail, nxt);
+    V8 pb0, pb1;
+    softmax(std::false_type{}, (int)cposc, blk, cur_tail, cur, nxt, pb0, pb1);
+    pv(cposc, pb0, pb1);
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  typedef std::integral_constant<int, 2> P2;
+  typedef std::integral_constant<int, 3> P3;
+  typedef std::integral_constant<int, 4> P4;
+  typedef std::integral_constant<int, 5> P5;
+
+  stage_sync();                            // stage 0 has landed
+  if (ns > 1) issue(1, std::false_type{});
+  if (active) {
+    f32x16 sa, sb;                         // the tiles of the even / odd blocks
+    {                                      // block 0: no running maximum yet - exact path, then the next tile against ITS maximum
+      V8 pb0, pb1;
+      softmax(std::true_type{}, 0, 0, nfullblk == 0, sa, sb, pb0, pb1);
+      next_tile(1, 1, 1 >= nfullblk, sb);
+      pv(P0{}, pb0, pb1);
+    }
+    int blk = 1;
+    for (; blk + 6 < nfullblk; blk += 6) {   // six blocks whose successors are all full blocks: positions 1 2 3 4 5 0
+      step(P1{}, P2{}, blk, false, false, sb, sa);
+      step(P2{}, P3{}, blk + 1, false, false, sa, sb);
+      step(P3{}, P4{}, blk + 2, false, false, sb, sa);
+      step(P4{}, P5{}, blk + 3, false, false, sa, sb);
+      step(P5{}, P0{}, blk + 4, false, false, sb, sa);
+      step(P0{}, P1{}, blk + 5, false, false, sa, sb);
+    }
+    while (blk < nblk) {                   // the rest (blk is odd here) on runtime positions
+      step(blk % 6, (blk + 1) % 6, blk, blk >= nfullblk, blk + 1 >= nfullblk, sb, sa);
+      ++blk;
+      if (blk < nblk) {
+        step(blk % 6, (blk + 1) % 6, blk, blk >= nfullblk, blk + 1 >= nfullblk, sa, sb);
+        ++blk;
+      }
+    }
+  } else {                                 // idle_stages: a wave past the end of the sequence keeps the workgroup's DMA and barriers going
+    for (int sn = 1; sn < ns; ++sn) {
+      stage_sync();
+      if (sn + 1 < ns) issue((sn + 1) % NBUF, std::true_type{});
+    }
+  }
+
+  const float lsum = half_pair_sum(l);
+  const float inv = 1.0f / lsum;
+  __builtin_amdgcn_s_barrier();                         // every wave is done with the stage buffers
+  asm volatile("" ::: "memory");
+  if (!active) return;
+  unsigned char* patch = &lds[0][0][0] + wave * 4096;
+  const unsigned xs = (unsigned)(((li >> 1) & 7) << 4);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    V4 a, cc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = from_f32<T>(o0[4 * g + i] * inv);
+      cc[i] = from_f32<T>(o1[4 * g + i] * inv);
+    }
+    *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(16 * g)) ^ xs) + 8 * hh) = a;
+    *reinterpret_cast<V4*>(patch + li * 128 + (((unsigned)(64 + 16 * g)) ^ xs) + 8 * hh) = cc;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int rq = lane >> 3, pq = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rq + 8 * i, q = q0 + row;
+    const V8 v = *reinterpret_cast<const V8*>(patch + row * 128 + 16 * (pq ^ ((row >> 1) & 7)));
+    if (q < Tn) *reinterpret_cast<V8*>(out + ((long)b * Tn + q) * heads * DH + (long)head * DH + 8 * pq) = v;
+  }
+}
+
 template <class T, int FLAGS = 0>
 static void launch_attention(const void* qkv, void* out, int B, int Tn, int heads, float scale, hipStream_t s,
                              int planar) {
   const int nqb = ceil_div(Tn, 32 * ATTN_NW);
+#if DSS_ATTN_PIPE
+  constexpr int PNW = DSS_ATTN_PIPE;       // lab: 8 = eight-wave workgroups at four waves per SIMD, 4 = four-wave workgroups at three
+  const int pnqb = ceil_div(Tn, 32 * PNW);
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, PNW>), dim3((unsigned)(pnqb * heads * B)), dim3(64 * PNW), 0, s, (const T*)qkv,
+                     (T*)out, Tn, heads, B, pnqb, scale * 1.4426950408889634f, planar);
+  (void)nqb;
+#else
   hipLaunchKernelGGL((attn_fwd_kernel<T, FLAGS, ATTN_NW>), dim3((unsigned)(nqb * heads * B)), dim3(64 * ATTN_NW), 0, s, (const T*)qkv,
                      (T*)out, Tn, heads, B, nqb, scale * 1.4426950408889634f, planar);
+#endif
 }
 
 }  // namespace dss
