@@ -1,26 +1,29 @@
 // gemm.hip - the Linear layers that are NOT hand-written kernels (mlp.fc2; at D = 768 also attn.proj and, at patch size 8, the
-// patch embedding) as hipBLASLt GEMMs with an algorithm this library chooses: never a Stream-K one.
+// patch embedding) as hipBLASLt GEMMs that are verified to run without Stream-K's partial-tile exchange.
 //
 // Replaces torch.nn.Linear inside DINO's Block / PatchEmbed (reached from extract/extract.py:94).
 //
 // Why this file exists (round 6; profiles/r06_forward_stress.txt): until round 5 these layers went through
-// PyTorch (`F.linear` -> hipblasLtMatmul with the library's first heuristic choice).  At the N = 768 shapes of dino_vitb8 /
-// dino_vitb16 that choice is a Stream-K kernel (`..._MT256x256x64_..._SK3_...`: output tiles split across workgroups, partial
-// sums exchanged through a workspace with flags), and that kernel is not reproducible on this stack: the SAME launch on the SAME
-// operands returned different values in whole 256-row tiles about once in 40 000 launches (26 of 42 000 dino_vitb8 forwards
-// differed across six configurations - also with every hand-written Linear kernel switched off -, the first differing tensor of a
-// captured event was fc2's output on bit-identical input, and 0 of 6 000 forwards differed with the library's Stream-K tiles
-// forced data-parallel).  The reference's forward is deterministic per input (extract/extract.py:94-98).  Here the candidates of
-// `hipblasLtMatmulAlgoGetHeuristic` are walked in the library's own order and the first one whose solution is neither Stream-K
-// (`_SK<n>_`, n > 0) nor split-K with atomic accumulation (`_GSU<n>_`, n > 1, unless multi-buffer `GSUAMB`) is taken: a
-// data-parallel kernel, every output tile written by one workgroup in a fixed order.  The choice is cached per problem.
+// PyTorch (`F.linear` -> hipblasLtMatmul with the library's first heuristic choice).  Every gfx950 kernel of this stack's
+// hipBLASLt is Stream-K-capable (`_SK3_` in every solution name): the kernel splits the last, partly filled round of output
+// tiles across workgroups and exchanges partial sums through a workspace with flags - and that exchange is not reproducible
+// here: the SAME launch on the SAME operands returned different values in whole 256-row tiles about once in 56 000 launches
+// (27 of 42 000 dino_vitb8 forwards differed across seven configurations - also with every hand-written Linear kernel switched
+// off -, the first differing tensor of a captured event was fc2's output on bit-identical input, and 0 of 6 000 forwards
+// differed with Tensile's `TENSILE_STREAMK_DATA_PARALLEL` switch).  The reference's forward is deterministic per input
+// (extract/extract.py:94-98).  Here the switch is set for the process before the handle exists, and it is VERIFIED per problem:
+// with it the library reports a workspace of 0 bytes for every candidate (without it 30-64 MiB: the partial-tile buffers), and a
+// candidate is only taken if it reports none (`deterministic_solution`) - otherwise the call fails loudly.  The candidates of
+// `hipblasLtMatmulAlgoGetHeuristic` are walked in the library's own order; the choice is cached per problem.
 //
 // State: one hipblasLt handle and the per-problem cache, created on first use, guarded by a mutex (the only persistent state of
-// the library besides the thread-local error string).  The workspace is the caller's.
+// the library besides the thread-local error string), and the one environment variable set (never read) for hipBLASLt.
 #include "common.h"
 
 #include <hipblaslt/hipblaslt.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
+
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -59,15 +62,19 @@ int name_field(const std::string& name, const char* key) {
   return -1;
 }
 
-// a solution whose result does not depend on the order in which workgroups finish, judged by the Tensile parameters its name
-// spells out (what this stack's names look like - profiles/r06_lt_describe.txt: the Stream-K one is
-// `Custom_Cijk_..._NTD_SK3_UserArgs_MT256x256x64_..._shortname0_gfx950`, the data-parallel ones carry `_GSU0_GSUAMB_` and no SK
-// field).  A candidate without a name is NOT taken: better to fail loudly on a build of hipBLASLt that gives none than to guess.
-// (A zero workspace budget does not work as the guard: on this stack nearly every data-parallel candidate reports a workspace too.)
-bool deterministic_solution(const std::string& name) {
-  if (name.empty()) return false;
-  if (name_field(name, "SK") > 0) return false;                     // Stream-K
-  if (name_field(name, "GSU") > 1 && name.find("GSUAMB") == std::string::npos) return false;   // split-K into one buffer
+// A candidate whose result cannot depend on the order in which workgroups finish.  On this stack EVERY gfx950 kernel of the
+// half-precision libraries is built Stream-K-capable (`_SK3_` in every solution name, the "data-parallel" `MT192x256x64` ones
+// included: profiles/r06_lt_describe.txt): the kernel itself splits the last, partly filled round of output tiles across
+// workgroups and exchanges partial sums through the workspace - that exchange is what is not reproducible.  What tells a launch
+// without it is the workspace the heuristic reports for the problem: 0 = no partial tiles, every output tile written by one
+// workgroup.  Tensile's own switch `TENSILE_STREAMK_DATA_PARALLEL` makes every launch such a one (the bisect arm with it: 0
+// differing forwards of 6 000); it is set for the process before the handle is created (ensure_handle, and
+// deep-spectral-segmentation_amd/__init__.py at import), and a candidate is taken only if the library then reports NO workspace for it - if
+// hipBLASLt was initialised before the switch could be set, nothing qualifies and the call fails loudly instead of running a
+// kernel that may be split.  Split-K into a single buffer (`_GSU<n>_`, n > 1, without `GSUAMB`) is refused by name as well.
+bool deterministic_solution(const std::string& name, size_t workspace) {
+  if (workspace != 0) return false;
+  if (name_field(name, "GSU") > 1 && name.find("GSUAMB") == std::string::npos) return false;
   return true;
 }
 
@@ -111,7 +118,10 @@ int build_problem(LtProblem& p, long M, int N, int K, int dtype, int out_dtype, 
 }
 
 int ensure_handle() {
-  if (!g_handle) DSS_LT(hipblasLtCreate(&g_handle));
+  if (!g_handle) {
+    setenv("TENSILE_STREAMK_DATA_PARALLEL", "1", 0);     // see deterministic_solution (no overwrite: a caller's explicit choice stands)
+    DSS_LT(hipblasLtCreate(&g_handle));
+  }
   return DSS_OK;
 }
 
@@ -134,7 +144,7 @@ int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // 
     // the library does not give one
     std::string name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, res[i].algo);
     if (name.empty()) name = hipblaslt_ext::getKernelNameFromAlgo(g_handle, res[i].algo);
-    const bool ok = res[i].state == HIPBLAS_STATUS_SUCCESS && deterministic_solution(name) && res[i].workspaceSize <= budget;
+    const bool ok = res[i].state == HIPBLAS_STATUS_SUCCESS && deterministic_solution(name, res[i].workspaceSize) && res[i].workspaceSize <= budget;
     if (log) {
       char head[112];
       snprintf(head, sizeof(head), "%s#%d state=%d ws=%zu idx=%d ", (ok && !found) ? "* " : (ok ? "  " : "x "), i, (int)res[i].state,
@@ -154,7 +164,8 @@ int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // 
   }
   if (!found) {
     if (log) { *log += "(no candidate taken)\n"; return DSS_OK; }      // dss_linear_lt_describe reports, dss_linear_lt fails
-    return fail(DSS_ERR_HIP, "dss_linear_lt: none of hipBLASLt's %d candidates is a data-parallel (non-Stream-K) solution", got);
+    return fail(DSS_ERR_HIP, "dss_linear_lt: none of hipBLASLt's %d candidates runs without a partial-tile workspace (Stream-K split "
+                "active: was hipBLASLt initialised in this process before TENSILE_STREAMK_DATA_PARALLEL=1 could be set?)", got);
   }
   return DSS_OK;
 }

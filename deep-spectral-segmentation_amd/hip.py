@@ -275,9 +275,9 @@ def _lt_workspace(device: torch.device) -> torch.Tensor:
 def linear_lt(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
               what: str = "") -> torch.Tensor:
     """``x [..., K] @ weight[N, K]^T (+ bias)`` for the Linear layers that are not hand-written kernels (fc2; at D = 768 also proj and
-    the patch-8 embedding): a hipBLASLt GEMM whose algorithm ``libdss_hip.so`` chooses - never a Stream-K solution (round 6: the
-    library's own first choice at the N = 768 shapes is not reproducible; ``dss_linear_lt`` in include/dss_hip.h).  f16 / bf16
-    operands, fp32 accumulation; ``out_dtype``: the operand type (default) or ``torch.float32``."""
+    the patch-8 embedding): a hipBLASLt GEMM that ``libdss_hip.so`` verifies to run without Stream-K's partial-tile exchange
+    (round 6: that exchange is not reproducible on this stack; ``dss_linear_lt`` in include/dss_hip.h).  f16 / bf16 operands,
+    fp32 accumulation; ``out_dtype``: the operand type (default) or ``torch.float32``."""
     k = x.shape[-1]
     n = weight.shape[0]
     assert weight.shape[1] == k and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
@@ -296,7 +296,7 @@ def linear_lt(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
 def linear_lt_describe(m: int, n: int, k: int, dtype: torch.dtype = torch.float16, out_dtype: Optional[torch.dtype] = None,
                        bias: bool = True) -> str:
     """hipBLASLt's candidate list for one GEMM problem as ``dss_linear_lt`` walks it: one line per candidate, '*' = the one taken,
-    'x' = passed over (Stream-K, atomic split-K, or workspace)."""
+    'x' = passed over (a partial-tile workspace, single-buffer split-K)."""
     buf = ctypes.create_string_buffer(1 << 16)
     lib = load_library()
     _check(lib.dss_linear_lt_describe(m, n, k, dtype_code(dtype), dtype_code(out_dtype or dtype), int(bias),

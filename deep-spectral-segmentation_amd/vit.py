@@ -127,11 +127,11 @@ class DinoViT:
         # within the box noise (822 -> 828 and 840 -> 844 images/s, same box each), and no standalone LayerNorm launch is left
         self.fuse_qkv768 = bool(fuse_qkv768)
         # library_gemm: who issues the Linear layers that are not hand-written kernels.  "lt" (default, round 6): dss_linear_lt - hipBLASLt
-        # with an algorithm chosen by libdss_hip.so, never a Stream-K solution (hipBLASLt's own first choice at the N = 768 shapes of
-        # the D = 768 models is one, and it is not reproducible: profiles/r06_forward_stress.txt).  "torch": F.linear, PyTorch's
-        # TunableOp table / hipBLASLt's first heuristic choice - rounds 1-5, kept as the A/B arm
+        # with its Stream-K split of the last round of tiles switched off AND verified off per problem (that split is not
+        # reproducible on this stack: profiles/r06_forward_stress.txt).  "torch": F.linear - rounds 1-5, kept as the A/B arm (the
+        # package import sets the same Tensile switch for the process, but nothing verifies it on this route)
         if library_gemm not in ("lt", "torch"):
-            raise ValueError("library_gemm must be 'lt' (dss_linear_lt: deterministic hipBLASLt algorithm) or 'torch' (F.linear)")
+            raise ValueError("library_gemm must be 'lt' (dss_linear_lt) or 'torch' (F.linear)")
         self.library_gemm = library_gemm
         d = self.embed_dim
         sd = state_dict
@@ -211,8 +211,8 @@ class DinoViT:
         blk, d = self.blocks[0], self.embed_dim
         k384 = bool(self.linear_k384) and d == 384
         kres_fc1 = self.gelu in ("erf", "erf_f16") and self.linear_k384 >= 2 and d in hip.LINEAR_KRES_WIDTHS
-        lib = ("library GEMM (hipBLASLt through dss_linear_lt: data-parallel algorithm)" if self.library_gemm == "lt"
-               else "library GEMM (hipBLASLt through F.linear: the library's first choice)")
+        lib = ("library GEMM (hipBLASLt through dss_linear_lt: no Stream-K split, verified)" if self.library_gemm == "lt"
+               else "library GEMM (hipBLASLt through F.linear)")
         return {
             "patch_embed": "dss_patch_embed_p16 (transform + GEMM + position rows, one kernel)" if self.pe16 is not None
                            else f"dss_preprocess_patchify + {lib} + add",

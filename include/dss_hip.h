@@ -12,7 +12,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Every call
  *     only ENQUEUES work on that stream and returns; nothing synchronises, nothing allocates.
  *   - Return value: DSS_OK (0) or a negative DSS_ERR_* code; dss_last_error() gives the message
- *     (thread-local).  Functions are re-entrant; there is no global mutable state and no environment variable is read.
+ *     (thread-local).  Functions are re-entrant; no environment variable is read; the only global state is dss_linear_lt's (see there).
  *   - Half-precision dtypes: DSS_F16 (IEEE binary16) / DSS_BF16; DSS_F32 where noted.
  */
 #ifndef DSS_HIP_H
@@ -106,18 +106,20 @@ int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int
 /* ---- a6: the Linear layers that are not hand-written kernels (mlp.fc2; at D = 768 also attn.proj and, at patch size 8, the
  * patch embedding) - torch.nn.Linear inside DINO's Block / PatchEmbed (reached from extract/extract.py:94):
  *     C[M, N] = A[M, K] . W[N, K]^T + bias[N]        (bias may be NULL)
- * as a hipBLASLt GEMM whose algorithm THIS library chooses (gemm.hip; round 6): the candidates of hipblasLtMatmulAlgoGetHeuristic
- * in the library's own order, the first that is neither a Stream-K solution nor a split-K one with atomic accumulation - a
- * data-parallel kernel, every output tile written by one workgroup, the same bits on every launch.  (hipBLASLt's first choice at
- * the N = 768 shapes of dino_vitb8 is a Stream-K kernel that is not reproducible on this stack: ~1 launch in 40 000 returns
- * different values in whole 256-row tiles; profiles/r06_forward_stress.txt.)  A, W, bias in `dtype` (DSS_F16 / DSS_BF16), row-major;
+ * as a hipBLASLt GEMM that is verified to run WITHOUT Stream-K's partial-tile exchange (gemm.hip; round 6).  Every gfx950 kernel
+ * of this stack's hipBLASLt splits the last, partly filled round of output tiles across workgroups through a workspace, and that
+ * exchange is not reproducible here (~1 launch in 56 000 returns different values in whole 256-row tiles:
+ * profiles/r06_forward_stress.txt).  The library sets Tensile's switch TENSILE_STREAMK_DATA_PARALLEL=1 for the process before
+ * it creates its hipblasLt handle (no overwrite) and takes, in the heuristic's own order, the first candidate for which hipBLASLt
+ * then reports a workspace of 0 bytes - every output tile written by one workgroup, the same bits on every launch; if no
+ * candidate does (hipBLASLt initialised earlier in the process without the switch), the call FAILS instead of running a split
+ * kernel.  A, W, bias in `dtype` (DSS_F16 / DSS_BF16), row-major;
  * C in `out_dtype` = `dtype` or DSS_F32 (the K projection keeps its fp32 accumulators); fp32 accumulation.  `workspace`: at least
- * dss_linear_lt_workspace_bytes() bytes the caller owns (128 MiB; may be shared by calls on one stream: nearly every
- * data-parallel candidate of this stack reports a workspace of 30-64 MiB).  A candidate is judged by the Tensile parameters in its
- * solution name (`_SK<n>_`, `_GSU<n>_`); one without a name is never taken.  The choice is cached per
+ * dss_linear_lt_workspace_bytes() bytes the caller owns (the upper bound a candidate may ask for; the ones taken ask for none).
+ * The choice is cached per
  * (M, N, K, dtypes, bias): the one hipblasLt handle and that cache are the library's only persistent state (mutex-guarded).
  * dss_linear_lt_describe writes the candidate list for a problem into buf, one line per candidate ('*' = the one taken,
- * 'x' = passed over: Stream-K, atomic split-K, no name, or a workspace beyond workspace_bytes). */
+ * 'x' = passed over: a partial-tile workspace, single-buffer split-K, or a workspace beyond workspace_bytes). */
 size_t dss_linear_lt_workspace_bytes(void);
 int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -9,9 +9,12 @@ this script checks what is left, on the compiler's own assembly:
 
   * no asm statement issues a register-returning GLOBAL load (LDS-DMA `global_load_lds_*` has no destination register);
   * between an asm `ds_read*` and the wait that covers it (LDS returns in order: `lgkmcnt(N)` covers every asm read older than the
-    N youngest), no instruction touches the destination registers.
+    N youngest), no instruction touches the destination registers;
+  * (round 6) a kernel that issues LDS-DMA (`global_load_lds_*`) has no scratch traffic at all: a spill reload shares vmcnt with the
+    DMA pieces, and the compiler's own `s_waitcnt vmcnt(0)` behind it then waits for the stage that was just issued (seen in the
+    pipelined attention lab kernel of round 6: twice as slow, results still right - nothing else would have flagged it).
 
-    python scripts/check_async_asm.py [file.s ...]      # default: compiles linear384.hip and attention.hip with -S (minutes)
+    python scripts/check_async_asm.py [file.s ...]      # default: compiles linear384.hip, attention.hip and affinity.hip with -S (minutes)
 Exit status 1 and one line per violation if any."""
 import os, re, subprocess, sys, tempfile
 
@@ -31,12 +34,21 @@ def regs_of(text):
 
 
 def check(path):
-    violations, stats = [], {"asm_ds_reads": 0, "functions": 0}
+    violations, stats = [], {"asm_ds_reads": 0, "functions": 0, "dma_kernels": 0}
     func, in_asm, pending = None, False, []          # pending: [(regs, line number)] of asm LDS reads not yet waited for
+    dma_at, scratch_at = None, None                  # first LDS-DMA / first scratch access of the running function
+
+    def close_function():
+        if dma_at is not None:
+            stats["dma_kernels"] += 1
+            if scratch_at is not None:
+                violations.append(f"{path}:{scratch_at}: {func}: scratch traffic in a kernel that issues LDS-DMA (first DMA at line {dma_at}): "
+                                  "spill reloads share vmcnt with the DMA pieces")
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if line[:1] not in " \t.;#" and s.endswith(":") or (line[:1] not in " \t.;#" and ": " in s and s.split(":")[0].startswith("_Z")):
-            func, pending, in_asm = s.split(":")[0], [], False
+            close_function()
+            func, pending, in_asm, dma_at, scratch_at = s.split(":")[0], [], False, None, None
             stats["functions"] += 1
             continue
         if s.startswith(";;#ASMSTART"):
@@ -49,6 +61,10 @@ def check(path):
             continue
         ins = s.split(";")[0].strip()
         op = ins.split()[0]
+        if in_asm and op.startswith("global_load_lds") and dma_at is None:
+            dma_at = ln
+        if op.startswith("scratch_") and scratch_at is None:
+            scratch_at = ln
         m = re.match(r"s_waitcnt\b.*lgkmcnt\((\d+)\)", ins)
         if m:
             n = int(m.group(1))
@@ -67,6 +83,7 @@ def check(path):
             dst = regs_of(ins.split(",")[0])
             pending.append((dst, ln))
             stats["asm_ds_reads"] += 1
+    close_function()
     return violations, stats
 
 
@@ -75,7 +92,10 @@ def main():
     tmp = None
     if not files:
         tmp = tempfile.mkdtemp()
-        for src, extra in (("linear384.hip", []), ("attention.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
+        # every source with an asm-pinned pipeline: the K-resident Linear family (all instantiations: K = 384 and K = 768, the fused
+        # LayerNorm prologues, the hand-over and patch-embedding modes), attention (K-fragment pipeline, LDS-DMA stages) and the
+        # affinity build (gram_f16_dma_kernel's LDS-DMA panels behind counted vmcnt waits)
+        for src, extra in (("linear384.hip", []), ("attention.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("affinity.hip", [])):
             out = os.path.join(tmp, src.replace(".hip", ".s"))
             subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "--cuda-device-only", "-S",
                             *extra, os.path.join(CSRC, src), "-o", out], check=True, stderr=subprocess.DEVNULL)
@@ -83,7 +103,8 @@ def main():
     bad = 0
     for f in files:
         v, st = check(f)
-        print(f"{os.path.basename(f)}: {st['functions']} functions, {st['asm_ds_reads']} asm LDS reads checked, {len(v)} violation(s)")
+        print(f"{os.path.basename(f)}: {st['functions']} functions, {st['asm_ds_reads']} asm LDS reads checked, {st['dma_kernels']} LDS-DMA kernels without scratch, "
+              f"{len(v)} violation(s)")
         for line in v[:40]:
             print("  " + line)
         bad += len(v)

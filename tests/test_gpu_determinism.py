@@ -86,9 +86,9 @@ def test_linear_kres_repeated_launches_give_the_same_bits(m, n, k, planar):
 @pytest.mark.parametrize("m,n,k", [(3601 * 24, 768, 3072), (3601 * 24, 768, 768), (3600 * 24, 768, 192), (901 * 290, 384, 1536)])
 def test_linear_lt_repeated_launches_give_the_same_bits(m, n, k):
     """dss_linear_lt at the library-GEMM shapes of the forward (fc2, proj and the patch-8 embedding of dino_vitb8; fc2 of the headline
-    model): a data-parallel hipBLASLt solution, the same bits on every launch.  (Through PyTorch's route the D = 768 shapes got a
-    Stream-K kernel: ~1 differing launch in 40 000 - too rare for 300 launches to see; the structural test is
-    tests/test_gpu_kernels.py::test_linear_lt_never_takes_a_stream_k_solution, the long form scripts/debug/forward_bisect.py.)"""
+    model): hipBLASLt with its Stream-K split switched off and verified off, the same bits on every launch.  (With the split
+    active the D = 768 shapes differ in ~1 launch of 56 000 - too rare for 300 launches to see; the structural test is
+    tests/test_gpu_kernels.py::test_linear_lt_only_takes_candidates_without_a_partial_tile_workspace, the long form scripts/debug/forward_bisect.py.)"""
     g = torch.Generator().manual_seed(k)
     a = _rand((m, k), 20)
     w, bias = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV), (torch.randn(n, generator=g) * 0.1).half().to(DEV)

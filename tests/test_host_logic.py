@@ -491,7 +491,9 @@ def test_inline_asm_pipelines_are_not_copied_before_their_wait():
     """scripts/check_async_asm.py on the compiler's assembly of the two kernels with inline-asm software pipelines: no asm
     statement issues a register-returning global load (the round-5 race of the fused norm -> Linear kernel: hipcc copied the
     destination register of such a load in front of the asm wait that covered it), and nothing touches the destination of an asm
-    LDS read between the read and the counted wait that covers it."""
+    LDS read between the read and the counted wait that covers it; round 6: affinity.hip is checked too, and no kernel that issues
+    LDS-DMA may have scratch traffic (a spill reload shares vmcnt with the DMA pieces: the rule is exercised on a handwritten
+    assembly fragment below, the product's 43 LDS-DMA kernels pass it)."""
     import shutil
     import subprocess
     import sys
@@ -499,7 +501,22 @@ def test_inline_asm_pipelines_are_not_copied_before_their_wait():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, str(REPO / "scripts" / "check_async_asm.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "linear384.s" in r.stdout and "attention.s" in r.stdout and " 0 violation(s)" in r.stdout
+    assert "linear384.s" in r.stdout and "attention.s" in r.stdout and "affinity.s" in r.stdout and " 0 violation(s)" in r.stdout
+    assert "LDS-DMA kernels without scratch" in r.stdout
+    # the rules fire on what they are meant to catch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_async_asm", REPO / "scripts" / "check_async_asm.py")
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = Path(os.environ.get("TMPDIR", "/tmp")) / f"dss_async_{os.getpid()}.s"
+    bad.write_text("_Zkernel_a:\n\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v1, s[2:3]\n\t;;#ASMEND\n\tscratch_load_dword v5, off, off offset:8\n\ts_endpgm\n"
+                   "_Zkernel_b:\n\t;;#ASMSTART\n\tds_read_b128 v[4:7], v9 offset:0\n\t;;#ASMEND\n\tv_mov_b32_e32 v20, v5\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+                   "_Zkernel_c:\n\t;;#ASMSTART\n\tglobal_load_dword v3, v1, s[2:3]\n\t;;#ASMEND\n\ts_endpgm\n")
+    try:
+        v, st = chk.check(str(bad))
+    finally:
+        bad.unlink()
+    assert len(v) == 3 and "scratch traffic" in v[0] + v[1] + v[2] and "before its wait" in v[0] + v[1] + v[2] and "register-returning" in v[0] + v[1] + v[2], v
 
 
 def test_scripts_compile():
