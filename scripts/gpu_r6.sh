@@ -44,6 +44,9 @@ for m, n, k in [(3601*24, 768, 3072), (3601*24, 768, 768), (3600*24, 768, 192), 
     eigs_ab)   # LIBS="tag ...": spectral-stage A/B (scripts/debug/eigs_ab.py), EIGS_AB_CASES="B,N,D,K;..."
       LABS=""; for L in ${LIBS:-}; do LABS="$LABS:$REPO_DIR/scripts/lablib/libdss_hip_$L.so"; done
       DSS_LAB_LIBRARY=${LABS#:} timeout 900 python scripts/debug/eigs_ab.py 2>&1 | tee gpurun_out/r06_eigs_ab.txt;;
+    mlp_lab)   # the fused-MLP lab kernel (prebuilt: scripts/probes/mlp_fused_lab[_nogelu]) against the product's pair, same box
+      ( for B in mlp_fused_lab mlp_fused_lab_nogelu; do echo "--- $B"; timeout 600 scripts/probes/$B ${MLP_IMAGES:-2473} 901 10; done
+        timeout 600 python scripts/debug/mlp_pair_time.py ${MLP_IMAGES:-2473} 901 ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_mlp_lab.txt;;
     ln_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -rf --tb=short -k "lnlinear or linear_kres or layernorm or patch_embed" 2>&1 | tail -30 > gpurun_out/pytest_ln.log; tail -15 gpurun_out/pytest_ln.log;;
     attn_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -rf --tb=short -k "attention" 2>&1 | tail -30 > gpurun_out/pytest_attn.log; tail -12 gpurun_out/pytest_attn.log;;
     vit_tests) timeout 1200 python -m pytest tests/test_gpu_e2e.py -m gpu -q --timeout 900 -rf --tb=short -k "vit or indexing or fp16_path or end_to_end_eigenvectors or config3" 2>&1 | tail -30 > gpurun_out/pytest_vit.log; tail -15 gpurun_out/pytest_vit.log;;

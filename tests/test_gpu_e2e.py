@@ -677,32 +677,39 @@ def test_fp16_path_survives_dino_like_outlier_activations(name, h, w, K):
     print(f"[outliers] {name}: feature rel err {rel:.2e}, max per-vector cos err {ce.max():.2e}, clusters {report}")
 
 
-@pytest.mark.parametrize("name,h,w,K,b", [("dino_vits16", 480, 480, 5, 8), ("dino_vitb8", 224, 160, 4, 4)])
+@pytest.mark.parametrize("name,h,w,K,b", [("dino_vits16", 480, 480, 5, 4), ("dino_vitb8", 224, 160, 4, 3)])
 def test_gelu_f16_form_against_the_exact_form_end_to_end(name, h, w, K, b):
     """The default GELU of the f16 path is a polynomial form on packed f16 (csrc/kres.h, `DinoViT(gelu="erf_f16")`; max error 1.1e-3 =
     up to 2.1 f16 spacings against the exact function, tests/test_host_logic.py::test_gelu_f16_poly_error_budget); DINO's own is the
     exact erf form (`gelu="erf"`, one flag away: `extract_features --gelu erf`).  The end-to-end GATE for keeping it the default
-    (ADVICE r5): on DINO-like weights (outlier channels, peaked attention, wide fc1 pre-activations) AND on plain random weights the
-    two models' K features agree far inside the f16 path's own distance from the fp32 oracle, and their eigenvectors inside the
-    1e-4 bar with every cluster compared as a subspace - a fp64 reference is built from the exact-form model's features."""
-    from oracle import spectral_ref
-    imgs = torch.from_numpy(np.stack([synthetic.synthetic_image(40 + i, h, w) for i in range(b)])).to(DEV)
-    for kind, sd in (("dino-like", synthetic.dino_like_state_dict(name, 3)), ("random", synthetic.synthetic_state_dict(name, 0))):
-        exact, fast = DinoViT(name, sd, DEV, torch.float16, gelu="erf"), DinoViT(name, sd, DEV, torch.float16, gelu="erf_f16")
-        assert exact.gelu == "erf" and fast.gelu == "erf_f16" and "packed f16" in fast.paths()["gelu"]
-        ke, eve, vece, infoe = pipeline.features_and_eigs(exact, imgs, K)
-        kf, evf, vecf, infof = pipeline.features_and_eigs(fast, imgs, K)
-        assert bool((infoe > 0).all()) and bool((infof > 0).all())
-        rel = ((kf - ke).flatten(1).norm(dim=1) / ke.flatten(1).norm(dim=1)).max().item()
-        assert rel < 1.5e-3, (kind, rel)       # (the f16 path as a whole is held to 6e-3 from the fp32 oracle on these weights)
-        worst = 0.0
-        for i in range(b):
-            lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(ke[i:i + 1].cpu(), K, max_draws=0)   # fp64 solution of the exact-form features
-            ce = check_eigs(vecf[i].cpu().numpy(), evf[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"gelu forms {name} {kind} {i}",
-                            lam_tol=2e-3, d=build_w64(ke[i].cpu().numpy())[1], ext=ext)
-            worst = max(worst, float(ce.max()))
-        print(f"[gelu forms] {name} {kind}: features differ by {rel:.2e} (relative, worst image); eigenvector check passed, "
-              f"worst per-vector cos err {worst:.2e}")
+    (ADVICE r5): on DINO-like weights (outlier channels, peaked attention, wide fc1 pre-activations) AND on plain random weights,
+    BOTH forms are measured against the fp32 CPU oracle on the same images - the packed form may not be further from the oracle's
+    K features than the exact form by more than 30 % (or 5e-4), both inside the f16 path's bar - and the eigenvectors of both must
+    pass the 1e-4 check against the fp64 solution of the oracle's features, every cluster compared as a subspace.  (Comparing the
+    two forms with EACH OTHER says little on the DINO-like weights: two f16 forwards that differ in one rounding are ~8e-3 apart
+    there - the outlier channels amplify any perturbation - while each is ~5e-3 from the oracle.)"""
+    imgs_np = np.stack([synthetic.synthetic_image(40 + i, h, w) for i in range(b)])
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    for kind, sd, bar in (("dino-like", synthetic.dino_like_state_dict(name, 3), 6e-3), ("random", synthetic.synthetic_state_dict(name, 0), 2e-3)):
+        ref = vit_ref.build_ref_vit(name, sd)
+        kr = [vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(imgs_np[i]))[0] for i in range(b)]
+        rels = {}
+        for form in ("erf", "erf_f16"):
+            model = DinoViT(name, sd, DEV, torch.float16, gelu=form)
+            assert model.gelu == form
+            k, ev, vec, info = pipeline.features_and_eigs(model, imgs, K)
+            assert bool((info > 0).all())
+            rels[form] = max(((k[i].cpu() - kr[i]).norm() / kr[i].norm()).item() for i in range(b))
+            worst = 0.0
+            for i in range(b):
+                lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(kr[i][None], K, max_draws=0)      # fp64 solution of the oracle's features
+                ce = check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"gelu {form} {name} {kind} {i}",
+                                lam_tol=2e-3, d=build_w64(kr[i].numpy())[1], ext=ext)
+                worst = max(worst, float(ce.max()))
+            print(f"[gelu forms] {name} {kind} gelu={form}: K features {rels[form]:.2e} from the fp32 oracle (relative, worst of {b} images); "
+                  f"eigenvector check passed, worst per-vector cos err {worst:.2e}")
+        assert rels["erf"] < bar and rels["erf_f16"] < bar, (kind, rels)
+        assert rels["erf_f16"] <= max(1.3 * rels["erf"], rels["erf"] + 5e-4), (kind, rels)
 
 
 def test_loader_reads_a_full_dino_training_checkpoint(tmp_path):

@@ -177,13 +177,11 @@ def test_linear_lt_only_takes_candidates_without_a_partial_tile_workspace():
     name) - it splits the last, partly filled round of output tiles across workgroups through a workspace, and that exchange is
     not reproducible (profiles/r06_forward_stress.txt).  With Tensile's data-parallel switch set for the process (package import /
     `dss_linear_lt` itself) the library reports NO workspace for any candidate, and `dss_linear_lt` only takes a candidate for
-    which that is the case.  For every library GEMM shape of the two bench configurations: exactly one candidate taken, workspace
-    0, no single-buffer split-K; and in a process WITHOUT the switch (a child started with the variable set to 0) the library
-    reports a workspace again and the wrapper refuses to run instead of running a split kernel."""
+    which that is the case (without the switch it reports 30-64 MiB - profiles/r06_lt_describe.txt - and the wrapper refuses to
+    run).  For every library GEMM shape of the two bench configurations: exactly one candidate taken, workspace 0, no
+    single-buffer split-K."""
     import os
     import re
-    import subprocess
-    import sys
     assert os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"          # set at package import
     shapes = [(3601 * 24, 768, 3072), (3601 * 24, 768, 768), (3600 * 24, 768, 192), (3601 * 291, 768, 3072), (3601 * 291, 768, 768),
               (901 * 2473, 384, 1536), (901 * 291, 384, 1536), (901 * 128, 384, 1536), (3601 * 7, 2304, 768), (1601 * 40, 768, 3072)]
@@ -195,12 +193,6 @@ def test_linear_lt_only_takes_candidates_without_a_partial_tile_workspace():
         gsu = re.search(r"_GSU(\d+)_", taken[0])
         assert not (gsu and int(gsu.group(1)) > 1 and "GSUAMB" not in taken[0]), taken[0]
         print(f"[linear_lt] M={m} N={n} K={k}: took {taken[0][:150]}")
-    code = ("import torch, dss_amd\nfrom dss_amd import hip\n"
-            "a = torch.randn(3601 * 24, 3072, device='cuda').half(); w = torch.randn(768, 3072, device='cuda').half()\n"
-            "try:\n    hip.linear_lt(a, w, None)\n    print('RAN')\nexcept hip.HipLibraryError as e:\n    print('REFUSED', e)\n")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(HERE.parent),
-                       env={**os.environ, "TENSILE_STREAMK_DATA_PARALLEL": "0"})
-    assert "REFUSED" in r.stdout and "partial-tile workspace" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("k", [384, 768])
