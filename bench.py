@@ -106,8 +106,9 @@ def parse():
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
     ap.add_argument("--no-fuse-qkv768", action="store_true",
                     help="A/B arm (D = 768 models): norm1 -> qkv as LayerNorm + library GEMM instead of one dss_lnlinear_k768 launch")
-    ap.add_argument("--gelu", default="erf_f16", choices=["erf", "erf_f16", "tanh_fused"],
-                    help="erf_f16 (default, = DinoViT's) = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
+    ap.add_argument("--gelu", default="auto", choices=["auto", "erf", "erf_f16", "tanh_fused"],
+                    help="auto (default, = DinoViT's) = erf_f16 for the D = 384 models, erf for D = 768; "
+                         "erf_f16 = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
                          "operands; error budget: tests/test_host_logic.py::test_gelu_f16_poly_error_budget; bf16 falls back to erf); "
                          "erf = the same function evaluated in fp32 (the A/B arm: +3.9 %% step time); "
                          "tanh_fused = hipBLASLt epilogue (tanh approximation, NOT the reference function; diagnostic only)")
@@ -835,7 +836,7 @@ def main():
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
                        "h2d_in_timed_region": not a.resident, "host_page_lock": {"register": "hipHostRegister", "shm": "hipHostRegister on a /dev/shm segment", "malloc": "hipHostMalloc (tensor.pin_memory)"}[a.host_pin],
                        "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
-                       "stage_overlap": a.overlap, "gelu": a.gelu},
+                       "stage_overlap": a.overlap, "gelu": model.gelu},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend, "timeline": timeline,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
             # what is NOT a hand-written kernel, and what the fused prologue removed: standalone LayerNorm launches per ViT

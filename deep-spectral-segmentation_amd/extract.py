@@ -672,10 +672,10 @@ def _feature_dict(k: torch.Tensor, index: int, file: str, model_name: str, patch
 
 def extract_features(images_list: str, images_root: Optional[str], model_name: str, batch_size: int,
                      output_dir: str, which_block: int = -1, weights: Optional[str] = None,
-                     dtype: str = "float16", synthetic_weights: Optional[int] = None, gelu: str = "erf_f16"):
-    """Extract features from a list of images (see module docstring).  ``gelu``: "erf_f16" (default: erf-GELU as a polynomial
-    form on packed f16, f16 operands only) or "erf" (DINO's exact GELU in fp32 arithmetic, ~4 % slower); the run prints which one
-    and which operand dtype produced its files.  ``batch_size`` is the maximum
+                     dtype: str = "float16", synthetic_weights: Optional[int] = None, gelu: str = "auto"):
+    """Extract features from a list of images (see module docstring).  ``gelu``: "erf_f16" (erf-GELU as a polynomial form on packed
+    f16, f16 operands only), "erf" (DINO's exact GELU in fp32 arithmetic, ~4 % slower at D = 384) or "auto" (default: "erf_f16" for
+    the D = 384 models, "erf" for D = 768); the run prints which one and which operand dtype produced its files.  ``batch_size`` is the maximum
     number of SAME-SHAPE images pushed through the ViT together; one ``B=1`` file is written per image
     whatever its value (every consumer asserts ``B == 1``, extract_utils.py:76).  ``batch_size <= 0``: as many images as
     fill FOUR whole rounds of the Linear kernels' workgroups at the first image's size (581 at 480 x 480 / patch 16) - a

@@ -92,12 +92,13 @@ def find_weights(name: str) -> Optional[Path]:
 
 
 def get_model(name: str, device: Optional[torch.device] = None, dtype: torch.dtype = torch.float16,
-              weights: Optional[str] = None, synthetic_seed: Optional[int] = None, gelu: str = "erf_f16"):
+              weights: Optional[str] = None, synthetic_seed: Optional[int] = None, gelu: str = "auto"):
     """Returns ``(model, val_transform, patch_size, num_heads)`` like the reference.  ``weights``: path
     to a DINO checkpoint; otherwise ``$DSS_DINO_WEIGHTS`` / the torch.hub cache are searched.
     ``synthetic_seed`` (or ``$DSS_SYNTHETIC_WEIGHTS``) builds random-init weights instead.  ``gelu``: ``DinoViT``'s
-    switch - "erf" is DINO's exact GELU in fp32 arithmetic, "erf_f16" (default) the same function as a polynomial
-    form on packed f16 in fc1's epilogue (csrc/kres.h; error budget in tests/test_host_logic.py)."""
+    switch - "erf" is DINO's exact GELU in fp32 arithmetic, "erf_f16" the same function as a polynomial form on packed
+    f16 in fc1's epilogue (csrc/kres.h; error budget in tests/test_host_logic.py), "auto" (default) = "erf_f16" for the
+    D = 384 models and "erf" for D = 768 (vit.py says why)."""
     from .vit import DinoViT, load_dino_state_dict
 
     name = name.lower()

@@ -679,37 +679,46 @@ def test_fp16_path_survives_dino_like_outlier_activations(name, h, w, K):
 
 @pytest.mark.parametrize("name,h,w,K,b", [("dino_vits16", 480, 480, 5, 4), ("dino_vitb8", 224, 160, 4, 3)])
 def test_gelu_f16_form_against_the_exact_form_end_to_end(name, h, w, K, b):
-    """The default GELU of the f16 path is a polynomial form on packed f16 (csrc/kres.h, `DinoViT(gelu="erf_f16")`; max error 1.1e-3 =
-    up to 2.1 f16 spacings against the exact function, tests/test_host_logic.py::test_gelu_f16_poly_error_budget); DINO's own is the
-    exact erf form (`gelu="erf"`, one flag away: `extract_features --gelu erf`).  The end-to-end GATE for keeping it the default
-    (ADVICE r5): on DINO-like weights (outlier channels, peaked attention, wide fc1 pre-activations) AND on plain random weights,
-    BOTH forms are measured against the fp32 CPU oracle on the same images - the packed form may not be further from the oracle's
-    K features than the exact form by more than 30 % (or 5e-4), both inside the f16 path's bar - and the eigenvectors of both must
-    pass the 1e-4 check against the fp64 solution of the oracle's features, every cluster compared as a subspace.  (Comparing the
-    two forms with EACH OTHER says little on the DINO-like weights: two f16 forwards that differ in one rounding are ~8e-3 apart
-    there - the outlier channels amplify any perturbation - while each is ~5e-3 from the oracle.)"""
+    """fc1's GELU has two forms on the f16 path: DINO's exact erf form in fp32 arithmetic (`gelu="erf"`) and a polynomial form on packed
+    f16 (`gelu="erf_f16"`: csrc/kres.h; max error 1.1e-3 = up to 2.1 f16 spacings, tests/test_host_logic.py::
+    test_gelu_f16_poly_error_budget; ~4 % faster at D = 384).  The end-to-end GATE that decides the default: on DINO-like
+    weights (outlier channels, peaked attention, wide fc1 pre-activations) AND on plain random weights BOTH forms are measured against
+    the fp32 CPU oracle on the same images - K features (relative) and eigenvectors (the 1e-4 check against the fp64 solution of the
+    oracle's features, every cluster compared as a subspace).  The form `DinoViT(gelu="auto")` picks for the model must pass
+    everything; the packed form, where it is the default, may not be further from the oracle's features than the exact form by more
+    than 30 % (or 5e-4).  Measured in round 6: D = 384 - 5.7e-4 against 5.3e-4 in the features, eigenvectors 6e-7 for both: packed
+    form by default; D = 768 (224 x 160 image, a near-degenerate edge cluster) - the exact form passes at 9.4e-5, the packed form
+    does not (1.5e-4): exact form by default.  (Comparing the two forms with EACH OTHER says little on the DINO-like weights: two
+    f16 forwards that differ in one rounding are ~8e-3 apart there while each is ~4e-3 from the oracle.)"""
     imgs_np = np.stack([synthetic.synthetic_image(40 + i, h, w) for i in range(b)])
     imgs = torch.from_numpy(imgs_np).to(DEV)
     for kind, sd, bar in (("dino-like", synthetic.dino_like_state_dict(name, 3), 6e-3), ("random", synthetic.synthetic_state_dict(name, 0), 2e-3)):
+        default = DinoViT(name, sd, DEV, torch.float16).gelu
+        assert default == ("erf_f16" if name == "dino_vits16" else "erf")
         ref = vit_ref.build_ref_vit(name, sd)
         kr = [vit_ref.ref_extract_k(ref, vit_ref.ref_preprocess(imgs_np[i]))[0] for i in range(b)]
-        rels = {}
+        rels, eig_fail = {}, {}
         for form in ("erf", "erf_f16"):
             model = DinoViT(name, sd, DEV, torch.float16, gelu=form)
             assert model.gelu == form
             k, ev, vec, info = pipeline.features_and_eigs(model, imgs, K)
             assert bool((info > 0).all())
             rels[form] = max(((k[i].cpu() - kr[i]).norm() / kr[i].norm()).item() for i in range(b))
-            worst = 0.0
+            worst, eig_fail[form] = 0.0, None
             for i in range(b):
                 lam, v, ext, _ = spectral_ref.ref_laplacian_eigs_ext(kr[i][None], K, max_draws=0)      # fp64 solution of the oracle's features
-                ce = check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"gelu {form} {name} {kind} {i}",
-                                lam_tol=2e-3, d=build_w64(kr[i].numpy())[1], ext=ext)
-                worst = max(worst, float(ce.max()))
-            print(f"[gelu forms] {name} {kind} gelu={form}: K features {rels[form]:.2e} from the fp32 oracle (relative, worst of {b} images); "
-                  f"eigenvector check passed, worst per-vector cos err {worst:.2e}")
-        assert rels["erf"] < bar and rels["erf_f16"] < bar, (kind, rels)
-        assert rels["erf_f16"] <= max(1.3 * rels["erf"], rels["erf"] + 5e-4), (kind, rels)
+                try:
+                    ce = check_eigs(vec[i].cpu().numpy(), ev[i].cpu().numpy(), v.numpy(), lam.numpy(), what=f"gelu {form} {name} {kind} {i}",
+                                    lam_tol=2e-3, d=build_w64(kr[i].numpy())[1], ext=ext)
+                    worst = max(worst, float(ce.max()))
+                except AssertionError as e:
+                    eig_fail[form] = str(e)[:300]
+            print(f"[gelu forms] {name} {kind} gelu={form}{' (default)' if form == default else ''}: K features {rels[form]:.2e} from the fp32 "
+                  f"oracle (relative, worst of {b} images); eigenvectors: " +
+                  (f"pass, worst per-vector cos err {worst:.2e}" if eig_fail[form] is None else "FAIL " + eig_fail[form]))
+        assert rels[default] < bar and eig_fail[default] is None, (kind, default, rels, eig_fail)
+        if default == "erf_f16":
+            assert rels["erf_f16"] <= max(1.3 * rels["erf"], rels["erf"] + 5e-4), (kind, rels)
 
 
 def test_loader_reads_a_full_dino_training_checkpoint(tmp_path):
