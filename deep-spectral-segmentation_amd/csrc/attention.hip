@@ -261,6 +261,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_kernel(const T* __restric
   static_assert(NW == 8 || NW == 4 || NW == 2, "a stage is eight 1 KB pieces per operand, shared evenly by the waves");
   const int q0 = qblk * (32 * NW) + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < Tn)) != 0;
+  // (Round 6 lab: dealing the 32-query tiles of an (image, head) EVENLY to its workgroups - T = 901: 8 + 7 + 7 + 7 instead of
+  //  8 + 8 + 8 + 5, T = 3601: 8 x 8 + 7 x 7 instead of 14 x 8 + 1 - measured equal to 0.3 %, same bits: the idle wave slots of the
+  //  last workgroup are not what the kernel is short of.  profiles/r06_attention_lab.txt.)
   DSS_CLOCK_BEGIN
 
   // ---- K/V stage DMA --------------------------------------------------------------------------------------------
