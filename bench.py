@@ -106,6 +106,11 @@ def parse():
                          "instead of the one dss_lnlinear_kfeatures_k384 kernel")
     ap.add_argument("--no-fuse-qkv768", action="store_true",
                     help="A/B arm (D = 768 models): norm1 -> qkv as LayerNorm + library GEMM instead of one dss_lnlinear_k768 launch")
+    ap.add_argument("--library-gemm", default="lt", choices=["lt", "torch", "torch-streamk"],
+                    help="who issues the Linear layers that are not hand-written kernels: lt (default) = dss_linear_lt (hipBLASLt, Stream-K "
+                         "split switched off and verified off); torch = F.linear (rounds 1-5; the package import still sets Tensile's "
+                         "data-parallel switch); torch-streamk = F.linear with that switch REMOVED from the environment before the first "
+                         "GEMM - rounds 1-5 exactly, not reproducible at D = 768 (A/B arm only)")
     ap.add_argument("--gelu", default="auto", choices=["auto", "erf", "erf_f16", "tanh_fused"],
                     help="auto (default, = DinoViT's) = erf_f16 for the D = 384 models, erf for D = 768; "
                          "erf_f16 = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
@@ -668,7 +673,10 @@ def main():
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[a.dtype]
     dim, depth, heads, patch = synthetic.VIT_CONFIGS[a.model]
     sd = synthetic.synthetic_state_dict(a.model, 0)
-    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
+    if a.library_gemm == "torch-streamk":
+        os.environ.pop("TENSILE_STREAMK_DATA_PARALLEL", None)
+    lib_gemm = "lt" if a.library_gemm == "lt" else "torch"
+    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
                     gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -836,7 +844,7 @@ def main():
                        "eig_arithmetic": "f32 Lanczos, f64 Rayleigh-Ritz",
                        "h2d_in_timed_region": not a.resident, "host_page_lock": {"register": "hipHostRegister", "shm": "hipHostRegister on a /dev/shm segment", "malloc": "hipHostMalloc (tensor.pin_memory)"}[a.host_pin],
                        "parallelism": f"dp{world} round-robin, 1 collection (sizes + flat payload, p2p)",
-                       "stage_overlap": a.overlap, "gelu": model.gelu},
+                       "stage_overlap": a.overlap, "gelu": model.gelu, "library_gemm": a.library_gemm},
             "ranks_seen": len(ranks_seen), "rank_devices": ranks_seen, "backend": backend, "timeline": timeline,
             "roofline": roofline, "kernels": kern, "unconverged_images": n_unconverged,
             # what is NOT a hand-written kernel, and what the fused prologue removed: standalone LayerNorm launches per ViT
@@ -865,7 +873,7 @@ def main():
     if world == 1 and a.companion_steps > 0 and a.dataset == 0 and model.gelu == "erf_f16":
         # the headline with DINO's exact erf-GELU in fp32 arithmetic instead of the packed-f16 polynomial form (both numbers
         # on the line; `extract_features --gelu erf` is this model)
-        me = DinoViT(a.model, sd, dev, dtype, gelu="erf", linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning,
+        me = DinoViT(a.model, sd, dev, dtype, gelu="erf", library_gemm=lib_gemm, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning,
                      fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
         for i in range(2):
             warm_step(me, a.w_dtype)
@@ -877,7 +885,7 @@ def main():
     if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
-        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, linear_kres=a.linear_kres,
+        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, linear_kres=a.linear_kres,
                      fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe,
                      fuse_qkv768=not a.no_fuse_qkv768)
         for i in range(2):

@@ -47,6 +47,10 @@ for m, n, k in [(3601*24, 768, 3072), (3601*24, 768, 768), (3600*24, 768, 192), 
     mlp_lab)   # the fused-MLP lab kernel (prebuilt: scripts/probes/mlp_fused_lab[_nogelu]) against the product's pair, same box
       ( for B in mlp_fused_lab mlp_fused_lab_nogelu; do echo "--- $B"; timeout 600 scripts/probes/$B ${MLP_IMAGES:-2473} 901 10; done
         timeout 600 python scripts/debug/mlp_pair_time.py ${MLP_IMAGES:-2473} 901 ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_mlp_lab.txt;;
+    two_ranks)   # the N > 1 code path on the one GPU of the box (gloo; both ranks share the GPU): weak line, then --dataset 2500
+      ( DSS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --cpu-images 0 --dino-like-steps 0 --companion-steps 0 --steps 6 2> gpurun_out/two_ranks.err
+        DSS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --dataset 2500 --cpu-images 0 --dino-like-steps 0 --companion-steps 0 2>> gpurun_out/two_ranks.err ) > gpurun_out/r06_bench_2ranks_one_gpu_gloo.json
+      tail -2 gpurun_out/two_ranks.err; cut -c1-200 gpurun_out/r06_bench_2ranks_one_gpu_gloo.json;;
     ln_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -rf --tb=short -k "lnlinear or linear_kres or layernorm or patch_embed" 2>&1 | tail -30 > gpurun_out/pytest_ln.log; tail -15 gpurun_out/pytest_ln.log;;
     attn_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -rf --tb=short -k "attention" 2>&1 | tail -30 > gpurun_out/pytest_attn.log; tail -12 gpurun_out/pytest_attn.log;;
     vit_tests) timeout 1200 python -m pytest tests/test_gpu_e2e.py -m gpu -q --timeout 900 -rf --tb=short -k "vit or indexing or fp16_path or end_to_end_eigenvectors or config3" 2>&1 | tail -30 > gpurun_out/pytest_vit.log; tail -15 gpurun_out/pytest_vit.log;;
