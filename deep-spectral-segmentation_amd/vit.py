@@ -99,8 +99,8 @@ class DinoViT:
             raise ValueError("gelu must be 'auto', 'erf' (DINO's exact GELU, fp32 arithmetic), 'erf_f16' (the same function evaluated on "
                              "packed f16: f16 operands and the K-resident fc1 kernel only) or 'tanh_fused'")
         # 'auto' (default, round 6): 'erf_f16' for the D = 384 models, 'erf' for D = 768.  The end-to-end gate
-        # (tests/test_gpu_e2e.py::test_gelu_f16_form_against_the_exact_form_end_to_end: both forms against the fp32 oracle on DINO-like
-        # weights) has the packed form 7 % further from the oracle than the exact one at D = 384 (5.7e-4 / 5.3e-4 in the features,
+        # (tests/test_gpu_e2e.py::test_gelu_f16_form_against_the_exact_form_end_to_end: both forms against the fp32 CPU reference on DINO-like
+        # weights) has the packed form 7 % further from that reference than the exact one at D = 384 (5.7e-4 / 5.3e-4 in the features,
         # eigenvectors 6e-7: nothing) - but at D = 768 the f16 path as a whole is close to the 1e-4 eigenvector bar on such weights
         # (exact form: 9.4e-5 in the worst edge cluster of a 224 x 160 image) and the packed form crosses it (1.5e-4): not the default there
         if gelu == "auto":

@@ -201,7 +201,7 @@ def test_wave_filling_batch_picks_whole_waves_of_workgroups():
             assert eff >= base - 1e-9                                    # never worse than the plain target
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03", "r04", "r05"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04", "r05", "r06"])
 def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_csvs(tmp_path, rnd):
     """profiles/rNN_pmc_traffic.json (what bench.py reads for roofline.traffic) must follow from the committed
     rocprofv3 counter summaries: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch."""
