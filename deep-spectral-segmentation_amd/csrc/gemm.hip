@@ -175,14 +175,16 @@ int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // 
 
 extern "C" size_t dss_linear_lt_workspace_bytes(void) { return (size_t)128 << 20; }   // (the candidates of this stack ask for up to 64 MiB)
 
-extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
-                             int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  using namespace dss;
-  DSS_REQUIRE(A && W && C, "dss_linear_lt: null pointer");
-  DSS_REQUIRE(M > 0 && N > 0 && K > 0, "dss_linear_lt: bad shape M=%ld N=%d K=%d", M, N, K);
-  DSS_REQUIRE(dtype == DSS_F16 || dtype == DSS_BF16, "dss_linear_lt: operand dtype must be DSS_F16 or DSS_BF16 (got %d)", dtype);
-  DSS_REQUIRE(out_dtype == dtype || out_dtype == DSS_F32, "dss_linear_lt: out_dtype must be the operand dtype or DSS_F32 (got %d)", out_dtype);
-  DSS_REQUIRE(workspace || workspace_bytes == 0, "dss_linear_lt: workspace_bytes > 0 with a null workspace");
+namespace dss {
+namespace {
+// C = A W^T + bias (beta = 0) or C += A W^T + bias (beta = 1, C fp32: the residual stream)
+int linear_lt_run(const char* who, const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
+                  int out_dtype, float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  DSS_REQUIRE(A && W && C, "%s: null pointer", who);
+  DSS_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape M=%ld N=%d K=%d", who, M, N, K);
+  DSS_REQUIRE(dtype == DSS_F16 || dtype == DSS_BF16, "%s: operand dtype must be DSS_F16 or DSS_BF16 (got %d)", who, dtype);
+  DSS_REQUIRE(out_dtype == dtype || out_dtype == DSS_F32, "%s: out_dtype must be the operand dtype or DSS_F32 (got %d)", who, out_dtype);
+  DSS_REQUIRE(workspace || workspace_bytes == 0, "%s: workspace_bytes > 0 with a null workspace", who);
   std::lock_guard<std::mutex> lock(g_mu);
   if (int rc = ensure_handle()) return rc;
   LtProblem p;
@@ -194,10 +196,22 @@ extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, voi
     if (int rc = choose(p, workspace_bytes, c, nullptr)) return rc;
     it = g_cache.insert_or_assign(key, c).first;
   }
-  const float alpha = 1.0f, beta = 0.0f;
+  const float alpha = 1.0f;
   DSS_LT(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &it->second.algo, workspace,
                          it->second.workspace, (hipStream_t)stream));
   return DSS_OK;
+}
+}  // namespace
+}  // namespace dss
+
+extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
+                             int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::linear_lt_run("dss_linear_lt", A, W, bias, C, M, N, K, dtype, out_dtype, 0.0f, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dss_linear_lt_accumulate(const void* A, const void* W, const void* bias, float* X, long M, int N, int K, int dtype,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  return dss::linear_lt_run("dss_linear_lt_accumulate", A, W, bias, X, M, N, K, dtype, DSS_F32, 1.0f, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_dtype, int has_bias, size_t workspace_bytes,

@@ -36,6 +36,8 @@ SYMBOLS = {
     "dss_linear_lt_workspace_bytes": (c_size_t, []),
     "dss_linear_lt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                               c_void_p]),
+    "dss_linear_lt_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_size_t,
+                                         c_void_p]),
     "dss_linear_lt_describe": (c_int, [ctypes.c_long, c_int, c_int, c_int, c_int, c_int, c_size_t, c_char_p, c_size_t]),
     "dss_lnlinear_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
@@ -291,6 +293,23 @@ def linear_lt(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
                                             _dev(out, "out"), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), ws.data_ptr(),
                                             ws.numel(), _stream()), "dss_linear_lt")
     return out
+
+
+def linear_lt_accumulate(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stream_x: torch.Tensor, what: str = "") -> torch.Tensor:
+    """``stream_x [..., N] (f32) += x [..., K] @ weight[N, K]^T (+ bias)`` in place (``dss_linear_lt_accumulate``): the Mlp branch
+    added to the fp32 residual stream inside the GEMM's own epilogue, from its fp32 accumulators."""
+    k = x.shape[-1]
+    n = weight.shape[0]
+    assert weight.shape[1] == k and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
+    assert bias is None or (bias.dtype == x.dtype and tuple(bias.shape) == (n,))
+    m = x.numel() // k
+    assert stream_x.dtype == torch.float32 and stream_x.numel() == m * n
+    ws = _lt_workspace(x.device)
+    with _timed("library_gemm", m=m, n=n, k=k, what=what):
+        _check(load_library().dss_linear_lt_accumulate(_dev(x, "x"), _dev(weight, "weight"), 0 if bias is None else _dev(bias, "bias"),
+                                                       _dev(stream_x, "stream_x"), m, n, k, dtype_code(x.dtype), ws.data_ptr(), ws.numel(),
+                                                       _stream()), "dss_linear_lt_accumulate")
+    return stream_x
 
 
 def linear_lt_describe(m: int, n: int, k: int, dtype: torch.dtype = torch.float16, out_dtype: Optional[torch.dtype] = None,

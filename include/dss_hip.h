@@ -25,13 +25,14 @@
 extern "C" {
 #endif
 
-/* 9: + dss_linear_lt / _workspace_bytes / _describe (round 6: the library GEMMs behind this ABI, never a Stream-K algorithm);
+/* 10: + dss_linear_lt_accumulate (the Mlp branch added to the fp32 residual stream inside the GEMM's epilogue);
+ * 9: + dss_linear_lt / _workspace_bytes / _describe (round 6: the library GEMMs behind this ABI, never a Stream-K algorithm);
  * 8: the packed storage of W gained the EDGE STRIP (below, at dss_affinity): a caller that only passes W from dss_affinity* to
  * dss_*_eigs* - every caller there is - is unaffected; one that builds or reads packed W itself must follow the layout of the
  * library it runs against (dss_affinity_elems(N) tells them apart: 106 * 4096 at N = 900 with the strip, 120 * 4096 without);
  * 7: + dss_lnlinear_kfeatures (D = 384 / 768, f16 / bf16 operands; round 5);  6: + dss_patch_embed_p16;  5: + dss_lnlinear_kfeatures_k384;  4: + dss_lnlinear_prepare / _k384 / _k768 (round 4).  Entry points are
  * only ever added: a caller built against version n runs against any library with dss_abi_version() >= n. */
-#define DSS_ABI_VERSION 9
+#define DSS_ABI_VERSION 10
 
 enum { DSS_F32 = 0, DSS_F16 = 1, DSS_BF16 = 2 };
 
@@ -125,6 +126,12 @@ int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long 
                   void* workspace, size_t workspace_bytes, void* stream);
 int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_dtype, int has_bias, size_t workspace_bytes, char* buf,
                            size_t buflen);
+/* The same GEMM ADDED to the fp32 residual stream in place - DINO Block's `x = x + mlp(...)` with the add inside the GEMM's own
+ * epilogue (extract/extract.py:94 -> Block.forward):   X[M, N] (f32) += A[M, K] . W[N, K]^T + bias[N]
+ * (hipBLASLt's beta = 1 with C = D = X: the branch output is added from the fp32 accumulators, never rounded to `dtype`, and the
+ * LayerNorm kernel behind it reads the finished stream - no pending branch output to add, no x write-back there).  ABI 10. */
+int dss_linear_lt_accumulate(const void* A, const void* W, const void* bias, float* X, long M, int N, int K, int dtype,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a6 + a6': residual add + LayerNorm + Linear in ONE kernel (DINO Block: `x = x + branch; h = norm(x); y = lin(h)`,
  * i.e. norm1 -> attn.qkv and norm2 -> mlp.fc1 (+ GELU); SURVEY.md Appendix A, reached from extract/extract.py:94).

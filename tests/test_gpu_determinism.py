@@ -95,6 +95,21 @@ def test_linear_lt_repeated_launches_give_the_same_bits(m, n, k):
     assert stress(lambda: [hip.linear_lt(a, w, bias)]) == (0, 0.0)
 
 
+@pytest.mark.parametrize("m,n,k", [(3601 * 24, 768, 3072), (901 * 290, 384, 1536)])
+def test_linear_lt_accumulate_repeated_launches_give_the_same_bits(m, n, k):
+    """fc2 adding into the fp32 residual stream (dss_linear_lt_accumulate): the stream is restored before every launch."""
+    g = torch.Generator().manual_seed(k + 1)
+    a = _rand((m, k), 21)
+    w, bias = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV), (torch.randn(n, generator=g) * 0.1).half().to(DEV)
+    x0 = _rand((m, n), 22, torch.float32, 2.0)
+    x = torch.empty_like(x0)
+
+    def fn():
+        x.copy_(x0)
+        return [hip.linear_lt_accumulate(a, w, bias, x)]
+    assert stress(fn) == (0, 0.0)
+
+
 @pytest.mark.parametrize("b,t,k", [(290, 901, 384), (16, 3601, 768)])
 def test_lnlinear_kfeatures_repeated_launches_give_the_same_bits(b, t, k):
     """kfeat_kres_kernel: the hooked block's norm1 -> K projection -> CLS drop / f16 copy / inverse norms."""

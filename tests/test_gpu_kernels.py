@@ -172,6 +172,27 @@ def test_linear_lt_matches_fp64_and_torch(m, n, k, bias, out32, dtype):
         assert (out - F.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV))).abs().max().item() <= 2 * tol
 
 
+@pytest.mark.parametrize("m,n,k", [(901 * 8, 384, 1536), (3601 * 4, 768, 3072), (77, 384, 1536)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_lt_accumulate_adds_into_the_fp32_stream(m, n, k, dtype):
+    """dss_linear_lt_accumulate: X (f32) += A W^T + b in place - DINO Block's `x = x + mlp(...)` inside fc2's own epilogue.  Against
+    fp64 on the rounded operands: the branch is added from the fp32 accumulators, so the error is fp32 accumulation error only (no
+    rounding of the branch output to the operand type: the bar is 50x tighter than dss_linear_lt's half-precision output)."""
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
+    b = (torch.randn(n, generator=g) * 0.1).to(dtype)
+    x0 = torch.randn(m, n, generator=g) * 3.0
+    x = x0.clone().to(DEV)
+    out = hip.linear_lt_accumulate(a.to(DEV), w.to(DEV), b.to(DEV), x)
+    assert out.data_ptr() == x.data_ptr()
+    ref = x0.double() + a.double() @ w.double().t() + b.double()
+    assert (x.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # and it is what the two-step form gives up to the half-precision rounding of the branch
+    two = x0.to(DEV) + hip.linear_lt(a.to(DEV), w.to(DEV), b.to(DEV)).float()
+    assert (x - two).abs().max().item() <= (1e-3 if dtype == torch.float16 else 8e-3) * max(1.0, (ref - x0.double()).abs().max().item())
+
+
 def test_linear_lt_only_takes_candidates_without_a_partial_tile_workspace():
     """The reason the wrapper exists: every gfx950 kernel of this stack's hipBLASLt is Stream-K-capable (`_SK3_` in every solution
     name) - it splits the last, partly filled round of output tiles across workgroups through a workspace, and that exchange is

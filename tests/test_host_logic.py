@@ -20,7 +20,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     lib = hip.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dss_abi_version() == 9 and lib.dss_target_arch() == b"gfx950"
+    assert lib.dss_abi_version() == 10 and lib.dss_target_arch() == b"gfx950"
     assert lib.dss_affinity_ld(900) == 960 and lib.dss_affinity_ld(64) == 64
     assert lib.dss_affinity_elems(900) == 106 * 4096 and lib.dss_affinity_elems(64) == 4096 and lib.dss_affinity_elems(960) == 120 * 4096
     assert lib.dss_eigs_workspace_bytes(1, 900, 5, 0) > 0
