@@ -111,9 +111,9 @@ def parse():
                          "split switched off and verified off); torch = F.linear (rounds 1-5; the package import still sets Tensile's "
                          "data-parallel switch); torch-streamk = F.linear with that switch REMOVED from the environment before the first "
                          "GEMM - rounds 1-5 exactly, not reproducible at D = 768 (A/B arm only)")
-    ap.add_argument("--no-fc2-into-stream", action="store_true",
-                    help="A/B arm: fc2's output leaves as a half-precision tensor and is added by the next LayerNorm prologue (rounds 4-5) instead "
-                         "of being added to the fp32 residual stream inside the GEMM's epilogue (dss_linear_lt_accumulate)")
+    ap.add_argument("--fc2-into-stream", action="store_true",
+                    help="A/B arm: fc2 adds its fp32 accumulators to the fp32 residual stream inside the GEMM's epilogue (dss_linear_lt_accumulate) "
+                         "instead of leaving a half-precision tensor for the next LayerNorm prologue to add (the default; rounds 4-6)")
     ap.add_argument("--gelu", default="auto", choices=["auto", "erf", "erf_f16", "tanh_fused"],
                     help="auto (default, = DinoViT's) = erf_f16 for the D = 384 models, erf for D = 768; "
                          "erf_f16 = DINO's erf-GELU as a polynomial form on packed f16 in fc1's epilogue (f16 "
@@ -679,7 +679,7 @@ def main():
     if a.library_gemm == "torch-streamk":
         os.environ.pop("TENSILE_STREAMK_DATA_PARALLEL", None)
     lib_gemm = "lt" if a.library_gemm == "lt" else "torch"
-    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, fc2_into_stream=not a.no_fc2_into_stream, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
+    model = DinoViT(a.model, sd, dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, fc2_into_stream=a.fc2_into_stream, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln,
                     gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
     n_patches = (a.size // patch) ** 2
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -876,7 +876,7 @@ def main():
     if world == 1 and a.companion_steps > 0 and a.dataset == 0 and model.gelu == "erf_f16":
         # the headline with DINO's exact erf-GELU in fp32 arithmetic instead of the packed-f16 polynomial form (both numbers
         # on the line; `extract_features --gelu erf` is this model)
-        me = DinoViT(a.model, sd, dev, dtype, gelu="erf", library_gemm=lib_gemm, fc2_into_stream=not a.no_fc2_into_stream, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning,
+        me = DinoViT(a.model, sd, dev, dtype, gelu="erf", library_gemm=lib_gemm, fc2_into_stream=a.fc2_into_stream, linear_kres=a.linear_kres, fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning,
                      fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe, fuse_qkv768=not a.no_fuse_qkv768)
         for i in range(2):
             warm_step(me, a.w_dtype)
@@ -888,7 +888,7 @@ def main():
     if world == 1 and a.dino_like_steps > 0 and a.dataset == 0:
         # the same workload with weights shaped like a trained DINO's (no checkpoint can be downloaded here): the ViT
         # costs the same, the eigensolver sees a harder spectrum - how much of the headline survives it
-        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, fc2_into_stream=not a.no_fc2_into_stream, linear_kres=a.linear_kres,
+        dl = DinoViT(a.model, synthetic.dino_like_state_dict(a.model, 0), dev, dtype, gelu=a.gelu, library_gemm=lib_gemm, fc2_into_stream=a.fc2_into_stream, linear_kres=a.linear_kres,
                      fuse_ln=not a.no_fuse_ln, gemm_tuning=a.gemm_tuning, fuse_k=not a.no_fuse_k, fuse_pe=not a.no_fuse_pe,
                      fuse_qkv768=not a.no_fuse_qkv768)
         for i in range(2):

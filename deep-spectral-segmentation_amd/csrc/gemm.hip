@@ -99,14 +99,14 @@ struct LtProblem {
 
 // C_rowmajor[M, N] = A[M, K] W[N, K]^T + bias: in column-major terms D[N, M] = op_T(W as [K, N]) . (A as [K, M]) - the problem
 // PyTorch's `F.linear` poses (TunableOp signature tn_<N>_<M>_<K>_ld_<K>_<K>_<N>)
-int build_problem(LtProblem& p, long M, int N, int K, int dtype, int out_dtype, const void* bias) {
+int build_problem(LtProblem& p, long M, int N, int K, int dtype, int out_dtype, const void* bias, int bias_dtype) {
   DSS_LT(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
   DSS_LT(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
   DSS_LT(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
   if (bias) {
     const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
-    const hipDataType bt = lt_type(dtype);
+    const hipDataType bt = lt_type(bias_dtype);
     DSS_LT(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
     DSS_LT(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
     DSS_LT(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
@@ -178,7 +178,7 @@ extern "C" size_t dss_linear_lt_workspace_bytes(void) { return (size_t)128 << 20
 namespace dss {
 namespace {
 // C = A W^T + bias (beta = 0) or C += A W^T + bias (beta = 1, C fp32: the residual stream)
-int linear_lt_run(const char* who, const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
+int linear_lt_run(const char* who, const void* A, const void* W, const void* bias, int bias_dtype, void* C, long M, int N, int K, int dtype,
                   int out_dtype, float beta, void* workspace, size_t workspace_bytes, void* stream) {
   DSS_REQUIRE(A && W && C, "%s: null pointer", who);
   DSS_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape M=%ld N=%d K=%d", who, M, N, K);
@@ -188,8 +188,8 @@ int linear_lt_run(const char* who, const void* A, const void* W, const void* bia
   std::lock_guard<std::mutex> lock(g_mu);
   if (int rc = ensure_handle()) return rc;
   LtProblem p;
-  if (int rc = build_problem(p, M, N, K, dtype, out_dtype, bias)) return rc;
-  const auto key = std::make_tuple(M, N, K, dtype, out_dtype, bias ? 1 : 0);
+  if (int rc = build_problem(p, M, N, K, dtype, out_dtype, bias, bias_dtype)) return rc;
+  const auto key = std::make_tuple(M, N, K, dtype, out_dtype, bias ? 1 + bias_dtype : 0);
   auto it = g_cache.find(key);
   if (it == g_cache.end() || it->second.workspace > workspace_bytes) {
     LtChoice c;
@@ -206,12 +206,13 @@ int linear_lt_run(const char* who, const void* A, const void* W, const void* bia
 
 extern "C" int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype,
                              int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  return dss::linear_lt_run("dss_linear_lt", A, W, bias, C, M, N, K, dtype, out_dtype, 0.0f, workspace, workspace_bytes, stream);
+  return dss::linear_lt_run("dss_linear_lt", A, W, bias, dtype, C, M, N, K, dtype, out_dtype, 0.0f, workspace, workspace_bytes, stream);
 }
 
-extern "C" int dss_linear_lt_accumulate(const void* A, const void* W, const void* bias, float* X, long M, int N, int K, int dtype,
+extern "C" int dss_linear_lt_accumulate(const void* A, const void* W, const float* bias, float* X, long M, int N, int K, int dtype,
                                         void* workspace, size_t workspace_bytes, void* stream) {
-  return dss::linear_lt_run("dss_linear_lt_accumulate", A, W, bias, X, M, N, K, dtype, DSS_F32, 1.0f, workspace, workspace_bytes, stream);
+  // (the bias is fp32 like the stream it is added to: with a half-precision bias vector hipBLASLt offers no solution for an fp32 C / D)
+  return dss::linear_lt_run("dss_linear_lt_accumulate", A, W, bias, DSS_F32, X, M, N, K, dtype, DSS_F32, 1.0f, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_dtype, int has_bias, size_t workspace_bytes,
@@ -224,7 +225,7 @@ extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_d
   if (int rc = ensure_handle()) return rc;
   LtProblem p;
   static const char dummy = 0;
-  if (int rc = build_problem(p, M, N, K, dtype, out_dtype, has_bias ? (const void*)&dummy : nullptr)) return rc;
+  if (int rc = build_problem(p, M, N, K, dtype, out_dtype, has_bias ? (const void*)&dummy : nullptr, out_dtype == DSS_F32 ? DSS_F32 : dtype)) return rc;
   LtChoice c;
   std::string log;
   if (int rc = choose(p, workspace_bytes, c, &log)) return rc;

@@ -301,7 +301,7 @@ def linear_lt_accumulate(x: torch.Tensor, weight: torch.Tensor, bias: Optional[t
     k = x.shape[-1]
     n = weight.shape[0]
     assert weight.shape[1] == k and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
-    assert bias is None or (bias.dtype == x.dtype and tuple(bias.shape) == (n,))
+    assert bias is None or (bias.dtype == torch.float32 and tuple(bias.shape) == (n,))     # fp32, like the stream
     m = x.numel() // k
     assert stream_x.dtype == torch.float32 and stream_x.numel() == m * n
     ws = _lt_workspace(x.device)

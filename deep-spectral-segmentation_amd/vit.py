@@ -85,7 +85,7 @@ class DinoViT:
     def __init__(self, model_name: str, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  dtype: torch.dtype = torch.float16, k_proj_fp32: bool = False, gelu: str = "auto",
                  linear_kres: int = 2, fuse_ln: bool = True, gemm_tuning: str = "table", fuse_k: bool = True, fuse_pe: bool = True,
-                 fuse_qkv768: bool = True, library_gemm: str = "lt", fc2_into_stream: bool = True):
+                 fuse_qkv768: bool = True, library_gemm: str = "lt", fc2_into_stream: bool = False):
         name = model_name.lower()
         if name not in VIT_CONFIGS:
             raise ValueError(f"Cannot get model: {model_name}")
@@ -140,12 +140,13 @@ class DinoViT:
         if library_gemm not in ("lt", "torch"):
             raise ValueError("library_gemm must be 'lt' (dss_linear_lt) or 'torch' (F.linear)")
         self.library_gemm = library_gemm
-        # fc2_into_stream (default with library_gemm = "lt"; round 6): `x = x + mlp(...)` inside fc2's own epilogue - the GEMM adds its fp32
-        # accumulators (+ bias) to the fp32 residual stream in place (dss_linear_lt_accumulate: hipBLASLt's beta = 1 with C = D = x).  The
-        # branch output is then never rounded to the operand type, and the norm1 -> qkv kernel of the NEXT block reads a finished stream:
-        # no pending branch output to add, no x write-back - 10 instead of 16 bytes per element through the most HBM-bound kernel of the
-        # forward, moved into a GEMM that has the headroom (same-box A/B: profiles/r06_ab_same_box.txt).  False: the branch output leaves as
-        # a `dtype` tensor and is added by the next LayerNorm prologue (rounds 4-5).
+        # fc2_into_stream (opt-in, needs library_gemm = "lt"; round 6): `x = x + mlp(...)` inside fc2's own epilogue - the GEMM adds its fp32
+        # accumulators (+ fp32 bias) to the fp32 residual stream in place (dss_linear_lt_accumulate: hipBLASLt's beta = 1 with C = D = x).
+        # The branch output is then never rounded to the operand type, and the norm1 -> qkv kernel of the NEXT block reads a finished
+        # stream (no pending branch output to add, no x write-back: 10 instead of 16 bytes per element through the most HBM-bound kernel
+        # of the forward).  Measured (profiles/r06_ab_same_box.txt): the bytes only MOVE - norm1 -> qkv 3.04 -> 2.55 ms per launch, fc2
+        # 2.70 -> 3.19 ms (its fp32 read-modify-write epilogue) - +0.1 ... 0.4 % end to end at C2 and C3: not the default; kept as a mode
+        # because it is the more accurate form (one rounding fewer per block).
         self.fc2_into_stream = bool(fc2_into_stream) and library_gemm == "lt"
         d = self.embed_dim
         sd = state_dict
@@ -184,7 +185,7 @@ class DinoViT:
                 proj_w=lp(sd[p + "attn.proj.weight"]), proj_b=lp(sd[p + "attn.proj.bias"]),
                 n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
                 fc1_w=lp(sd[p + "mlp.fc1.weight"]), fc1_b=lp(sd[p + "mlp.fc1.bias"]),
-                fc2_w=lp(sd[p + "mlp.fc2.weight"]), fc2_b=lp(sd[p + "mlp.fc2.bias"]),
+                fc2_w=lp(sd[p + "mlp.fc2.weight"]), fc2_b=lp(sd[p + "mlp.fc2.bias"]), fc2_b32=f32(sd[p + "mlp.fc2.bias"]),
             ))
         hip.load_library()  # fail now, not mid-run, if the kernels are missing
         if self.fuse_ln and self.linear_k384 and d in hip.LINEAR_KRES_WIDTHS:
@@ -313,7 +314,7 @@ class DinoViT:
                     f1 = torch._addmm_activation(blk["fc1_b"], hcur.view(b * t, d), blk["fc1_w"].t(),
                                                  use_gelu=True).view(b, t, -1)
             if self.fc2_into_stream:
-                hip.linear_lt_accumulate(f1, blk["fc2_w"], blk["fc2_b"], x, what="fc2")     # x += fc2(f1) + b, fp32, in place
+                hip.linear_lt_accumulate(f1, blk["fc2_w"], blk["fc2_b32"], x, what="fc2")     # x += fc2(f1) + b, fp32, in place
                 pending = None
             else:
                 pending = self._linear(f1, blk["fc2_w"], blk["fc2_b"], "fc2")

@@ -129,8 +129,9 @@ int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_dtype, int h
 /* The same GEMM ADDED to the fp32 residual stream in place - DINO Block's `x = x + mlp(...)` with the add inside the GEMM's own
  * epilogue (extract/extract.py:94 -> Block.forward):   X[M, N] (f32) += A[M, K] . W[N, K]^T + bias[N]
  * (hipBLASLt's beta = 1 with C = D = X: the branch output is added from the fp32 accumulators, never rounded to `dtype`, and the
- * LayerNorm kernel behind it reads the finished stream - no pending branch output to add, no x write-back there).  ABI 10. */
-int dss_linear_lt_accumulate(const void* A, const void* W, const void* bias, float* X, long M, int N, int K, int dtype,
+ * LayerNorm kernel behind it reads the finished stream - no pending branch output to add, no x write-back there).  `bias` is
+ * fp32 like the stream (or NULL).  ABI 10. */
+int dss_linear_lt_accumulate(const void* A, const void* W, const float* bias, float* X, long M, int N, int K, int dtype,
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a6 + a6': residual add + LayerNorm + Linear in ONE kernel (DINO Block: `x = x + branch; h = norm(x); y = lin(h)`,

@@ -100,7 +100,7 @@ def test_linear_lt_accumulate_repeated_launches_give_the_same_bits(m, n, k):
     """fc2 adding into the fp32 residual stream (dss_linear_lt_accumulate): the stream is restored before every launch."""
     g = torch.Generator().manual_seed(k + 1)
     a = _rand((m, k), 21)
-    w, bias = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV), (torch.randn(n, generator=g) * 0.1).half().to(DEV)
+    w, bias = (torch.randn(n, k, generator=g) * 0.05).half().to(DEV), (torch.randn(n, generator=g) * 0.1).to(DEV)
     x0 = _rand((m, n), 22, torch.float32, 2.0)
     x = torch.empty_like(x0)
 

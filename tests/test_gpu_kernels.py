@@ -181,7 +181,7 @@ def test_linear_lt_accumulate_adds_into_the_fp32_stream(m, n, k, dtype):
     g = torch.Generator().manual_seed(m + n)
     a = torch.randn(m, k, generator=g).to(dtype)
     w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
-    b = (torch.randn(n, generator=g) * 0.1).to(dtype)
+    b = torch.randn(n, generator=g) * 0.1           # fp32, like the stream
     x0 = torch.randn(m, n, generator=g) * 3.0
     x = x0.clone().to(DEV)
     out = hip.linear_lt_accumulate(a.to(DEV), w.to(DEV), b.to(DEV), x)
@@ -189,7 +189,7 @@ def test_linear_lt_accumulate_adds_into_the_fp32_stream(m, n, k, dtype):
     ref = x0.double() + a.double() @ w.double().t() + b.double()
     assert (x.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     # and it is what the two-step form gives up to the half-precision rounding of the branch
-    two = x0.to(DEV) + hip.linear_lt(a.to(DEV), w.to(DEV), b.to(DEV)).float()
+    two = x0.to(DEV) + hip.linear_lt(a.to(DEV), w.to(DEV), b.to(dtype).to(DEV)).float()
     assert (x - two).abs().max().item() <= (1e-3 if dtype == torch.float16 else 8e-3) * max(1.0, (ref - x0.double()).abs().max().item())
 
 
