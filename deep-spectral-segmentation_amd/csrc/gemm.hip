@@ -14,7 +14,9 @@
 // (extract/extract.py:94-98).  Here the switch is set for the process before the handle exists, and it is VERIFIED per problem:
 // with it the library reports a workspace of 0 bytes for every candidate (without it 30-64 MiB: the partial-tile buffers), and a
 // candidate is only taken if it reports none (`deterministic_solution`) - otherwise the call fails loudly.  The candidates of
-// `hipblasLtMatmulAlgoGetHeuristic` are walked in the library's own order; the choice is cached per problem.
+// `hipblasLtMatmulAlgoGetHeuristic` are walked in the library's own order - the first qualifying one is taken, unless a MEASURED
+// preference names a tile shape for the problem class and a qualifying candidate has it (`kPreferred`) -; the choice is cached per
+// problem.
 //
 // State: one hipblasLt handle and the per-problem cache, created on first use, guarded by a mutex (the only persistent state of
 // the library besides the thread-local error string), and the one environment variable set (never read) for hipBLASLt.
@@ -39,7 +41,7 @@ struct LtChoice {
   size_t workspace;
   std::string name;       // solution name of the choice
   int rank;               // its position in the heuristic's list (0 = the library's own first choice)
-  int rejected;           // Stream-K / atomic split-K candidates passed over in front of it
+  int rejected;           // candidates in front of it that did not qualify (workspace, atomic split-K)
 };
 
 std::mutex g_mu;
@@ -76,6 +78,24 @@ bool deterministic_solution(const std::string& name, size_t workspace) {
   if (workspace != 0) return false;
   if (name_field(name, "GSU") > 1 && name.find("GSUAMB") == std::string::npos) return false;
   return true;
+}
+
+// Measured preferences (profiles/r06_lt_tune.txt: every solution the library bundled with PyTorch 2.10+rocm7.0 has for the problem,
+// timed on MI355X inside a process that imported torch).  The heuristic's first choice is not always its fastest kernel: for mlp.fc2
+// at D = 384 (N = 384, K = 1536) the 192 x 128 tile is 13.5 % faster than the 192 x 256 one the heuristic puts first at 2.2 M rows,
+// 6.4 % at 1.1 M, 6.5 % at 262 k, 3.2 % at 86 k - and returns the same bits (so do 194 of the 227 solutions that support the
+// problem).  In place, on real activations, it is worth 2.2 % of the fc2 site (same-box A/B, three rounds) - operand data move the
+// clock, and synthetic operands overstate the difference.  A preference is a tile shape looked for AMONG THE HEURISTIC'S OWN CANDIDATES, under the same no-workspace rule; where
+// no candidate has it (another build of the library) the walk takes the first qualifying candidate as before.  Shapes whose
+// fastest kernel changes with the row count (attn.proj at D = 768: -9 % at 1.05 M rows, +27 % at 262 k) have no entry.
+struct LtPreference { int N, K, dtype, out_dtype; long min_M; const char* tile; };
+constexpr LtPreference kPreferred[] = {
+    {384, 1536, DSS_F16, DSS_F16, 65536, "_MT192x128x64_MI16x16x1_"},
+};
+const char* preferred_tile(long M, int N, int K, int dtype, int out_dtype) {
+  for (const LtPreference& p : kPreferred)
+    if (p.N == N && p.K == K && p.dtype == dtype && p.out_dtype == out_dtype && M >= p.min_M) return p.tile;
+  return nullptr;
 }
 
 hipDataType lt_type(int dtype) { return dtype == DSS_F16 ? HIP_R_16F : dtype == DSS_BF16 ? HIP_R_16BF : HIP_R_32F; }
@@ -125,8 +145,9 @@ int ensure_handle() {
   return DSS_OK;
 }
 
-// walks the heuristic's candidates; `log` (optional) receives one line per candidate
-int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // budget: the caller's workspace
+// walks the heuristic's candidates; `prefer` (optional): the tile shape of a measured preference; `log` (optional) receives one
+// line per candidate
+int choose(LtProblem& p, size_t budget, const char* prefer, LtChoice& out, std::string* log) {   // budget: the caller's workspace
   hipblasLtMatmulPreference_t pref = nullptr;
   DSS_LT(hipblasLtMatmulPreferenceCreate(&pref));
   hipblasStatus_t st = hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &budget, sizeof(budget));
@@ -137,36 +158,40 @@ int choose(LtProblem& p, size_t budget, LtChoice& out, std::string* log) {   // 
     st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, WANT, res.data(), &got);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS) return fail(DSS_ERR_HIP, "hipblasLtMatmulAlgoGetHeuristic failed with hipblasStatus %d", (int)st);
-  bool found = false;
-  int rejected = 0;
+  std::vector<std::string> names(got);
+  std::vector<char> ok(got, 0);
+  int first = -1, wanted = -1;
   for (int i = 0; i < got; ++i) {
     // the solution name carries every Tensile parameter (`_SK3_`, `_GSU2_`, ...); the kernel name is the fallback where a build of
     // the library does not give one
-    std::string name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, res[i].algo);
-    if (name.empty()) name = hipblaslt_ext::getKernelNameFromAlgo(g_handle, res[i].algo);
-    const bool ok = res[i].state == HIPBLAS_STATUS_SUCCESS && deterministic_solution(name, res[i].workspaceSize) && res[i].workspaceSize <= budget;
-    if (log) {
-      char head[112];
-      snprintf(head, sizeof(head), "%s#%d state=%d ws=%zu idx=%d ", (ok && !found) ? "* " : (ok ? "  " : "x "), i, (int)res[i].state,
-               res[i].workspaceSize, hipblaslt_ext::getIndexFromAlgo(res[i].algo));
-      *log += head + (name.empty() ? std::string("<no name>") : name) + "\n";
-    }
-    if (ok && !found) {
-      out.algo = res[i].algo;
-      out.workspace = res[i].workspaceSize;
-      out.name = name;
-      out.rank = i;
-      out.rejected = rejected;
-      found = true;
-      if (!log) break;
-    }
-    if (!ok) ++rejected;
+    names[i] = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, res[i].algo);
+    if (names[i].empty()) names[i] = hipblaslt_ext::getKernelNameFromAlgo(g_handle, res[i].algo);
+    ok[i] = res[i].state == HIPBLAS_STATUS_SUCCESS && deterministic_solution(names[i], res[i].workspaceSize) && res[i].workspaceSize <= budget;
+    if (ok[i] && first < 0) first = i;
+    if (ok[i] && wanted < 0 && prefer && names[i].find(prefer) != std::string::npos) wanted = i;
+    if (first >= 0 && !log && (!prefer || wanted >= 0)) break;
   }
-  if (!found) {
+  const int take = wanted >= 0 ? wanted : first;
+  if (log) {
+    for (int i = 0; i < got; ++i) {
+      char head[128];
+      snprintf(head, sizeof(head), "%s#%d state=%d ws=%zu idx=%d ", i == take ? (i == wanted ? "*p" : "* ") : (ok[i] ? "  " : "x "), i, (int)res[i].state,
+               res[i].workspaceSize, hipblaslt_ext::getIndexFromAlgo(res[i].algo));
+      *log += head + (names[i].empty() ? std::string("<no name>") : names[i]) + "\n";
+    }
+    if (prefer) *log += std::string("(measured preference for this problem class: ") + prefer + (wanted >= 0 ? ": taken, marked *p)\n" : ": not among the candidates)\n");
+  }
+  if (take < 0) {
     if (log) { *log += "(no candidate taken)\n"; return DSS_OK; }      // dss_linear_lt_describe reports, dss_linear_lt fails
     return fail(DSS_ERR_HIP, "dss_linear_lt: none of hipBLASLt's %d candidates runs without a partial-tile workspace (Stream-K split "
                 "active: was hipBLASLt initialised in this process before TENSILE_STREAMK_DATA_PARALLEL=1 could be set?)", got);
   }
+  out.algo = res[take].algo;
+  out.workspace = res[take].workspaceSize;
+  out.name = names[take];
+  out.rank = take;
+  out.rejected = 0;
+  for (int i = 0; i < take; ++i) out.rejected += !ok[i];
   return DSS_OK;
 }
 
@@ -193,7 +218,7 @@ int linear_lt_run(const char* who, const void* A, const void* W, const void* bia
   auto it = g_cache.find(key);
   if (it == g_cache.end() || it->second.workspace > workspace_bytes) {
     LtChoice c;
-    if (int rc = choose(p, workspace_bytes, c, nullptr)) return rc;
+    if (int rc = choose(p, workspace_bytes, preferred_tile(M, N, K, dtype, out_dtype), c, nullptr)) return rc;
     it = g_cache.insert_or_assign(key, c).first;
   }
   const float alpha = 1.0f;
@@ -228,7 +253,7 @@ extern "C" int dss_linear_lt_describe(long M, int N, int K, int dtype, int out_d
   if (int rc = build_problem(p, M, N, K, dtype, out_dtype, has_bias ? (const void*)&dummy : nullptr, out_dtype == DSS_F32 ? DSS_F32 : dtype)) return rc;
   LtChoice c;
   std::string log;
-  if (int rc = choose(p, workspace_bytes, c, &log)) return rc;
+  if (int rc = choose(p, workspace_bytes, preferred_tile(M, N, K, dtype, out_dtype), c, &log)) return rc;
   snprintf(buf, buflen, "%s", log.c_str());
   return DSS_OK;
 }

@@ -119,8 +119,10 @@ int dss_linear_k768(const void* A, const void* W, const void* bias, void* C, int
  * dss_linear_lt_workspace_bytes() bytes the caller owns (the upper bound a candidate may ask for; the ones taken ask for none).
  * The choice is cached per
  * (M, N, K, dtypes, bias): the one hipblasLt handle and that cache are the library's only persistent state (mutex-guarded).
- * dss_linear_lt_describe writes the candidate list for a problem into buf, one line per candidate ('*' = the one taken,
- * 'x' = passed over: a partial-tile workspace, single-buffer split-K, or a workspace beyond workspace_bytes). */
+ * Among the qualifying candidates the first is taken, unless a MEASURED preference names a tile shape for the problem class and a
+ * qualifying candidate has it (one entry so far: N = 384, K = 1536, f16, from 65 536 rows - profiles/r06_lt_tune.txt).
+ * dss_linear_lt_describe writes the candidate list for a problem into buf, one line per candidate ('* ' = the one taken, '*p' = taken
+ * by a measured preference, 'x' = passed over: a partial-tile workspace, single-buffer split-K, or a workspace beyond workspace_bytes). */
 size_t dss_linear_lt_workspace_bytes(void);
 int dss_linear_lt(const void* A, const void* W, const void* bias, void* C, long M, int N, int K, int dtype, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -153,7 +153,8 @@ def test_gelu_f16_epilogue_is_the_documented_arithmetic_bit_for_bit(k):
 # ----------------------------------------------------------------------------- library GEMMs behind the ABI (round 6)
 @pytest.mark.parametrize("m,n,k,bias,out32", [(901 * 8, 384, 1536, True, False), (3601 * 4, 768, 3072, True, False), (3600 * 3, 768, 192, True, False),
                                              (3601 * 2, 768, 768, True, False), (3601 * 2, 2304, 768, True, False), (901 * 3, 384, 384, False, True),
-                                             (1, 384, 1536, True, False), (77, 768, 768, False, True)])
+                                             (1, 384, 1536, True, False), (77, 768, 768, False, True),
+                                             (901 * 80, 384, 1536, True, False)])         # (from 65 536 rows: the measured tile preference)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_linear_lt_matches_fp64_and_torch(m, n, k, bias, out32, dtype):
     """dss_linear_lt (hipBLASLt with a data-parallel algorithm chosen by the library): x W^T + b against fp64 on the rounded operands
@@ -200,16 +201,24 @@ def test_linear_lt_only_takes_candidates_without_a_partial_tile_workspace():
     `dss_linear_lt` itself) the library reports NO workspace for any candidate, and `dss_linear_lt` only takes a candidate for
     which that is the case (without the switch it reports 30-64 MiB - profiles/r06_lt_describe.txt - and the wrapper refuses to
     run).  For every library GEMM shape of the two bench configurations: exactly one candidate taken, workspace 0, no
-    single-buffer split-K."""
+    single-buffer split-K.  Where a measured preference exists (mlp.fc2 at D = 384 from 65 536 rows: the 192 x 128 tile,
+    profiles/r06_lt_tune.txt) the taken line is marked `*p` and carries that tile - IF the library offers it among its candidates
+    (the build bundled with this image's PyTorch does); below the row threshold and for every other shape no preference is stated."""
     import os
     import re
     assert os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1"          # set at package import
     shapes = [(3601 * 24, 768, 3072), (3601 * 24, 768, 768), (3600 * 24, 768, 192), (3601 * 291, 768, 3072), (3601 * 291, 768, 768),
-              (901 * 2473, 384, 1536), (901 * 291, 384, 1536), (901 * 128, 384, 1536), (3601 * 7, 2304, 768), (1601 * 40, 768, 3072)]
+              (901 * 2473, 384, 1536), (901 * 291, 384, 1536), (901 * 128, 384, 1536), (901 * 64, 384, 1536), (3601 * 7, 2304, 768), (1601 * 40, 768, 3072)]
     for m, n, k in shapes:
         text = hip.linear_lt_describe(m, n, k, torch.float16)
-        taken = [ln for ln in text.splitlines() if ln.startswith("* ")]
+        taken = [ln for ln in text.splitlines() if ln.startswith("* ") or ln.startswith("*p")]
         assert len(taken) == 1, text
+        has_preference = (n, k) == (384, 1536) and m >= 65536
+        assert ("measured preference" in text) == has_preference, text
+        if taken[0].startswith("*p"):
+            assert has_preference and "_MT192x128x64_MI16x16x1_" in taken[0], taken[0]
+        elif has_preference:
+            assert "not among the candidates" in text, text
         assert " ws=0 " in taken[0], taken[0]
         gsu = re.search(r"_GSU(\d+)_", taken[0])
         assert not (gsu and int(gsu.group(1)) > 1 and "GSUAMB" not in taken[0]), taken[0]
