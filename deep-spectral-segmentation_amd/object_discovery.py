@@ -49,30 +49,39 @@ def get_largest_cc_box(mask: np.ndarray):
     return [int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1]
 
 
+# How a mask of T elements maps onto the padded image (object_discovery.py:88-99), in the reference's order of preference:
+# (patch stride of the ViT grid the mask derives from, upsampling factor of the mask over that grid) -> the box scale is
+# stride / upsample pixels per mask cell.  Patch 8; patch 16; patch 16 upsampled 2x; patch 32 upsampled 4x.
+_MASK_GRIDS = ((8, 1), (16, 1), (16, 2), (32, 4))
+
+
+def _mask_grid(height: int, width: int, cells: int):
+    """(pixels per mask cell, mask rows, mask columns) of the first entry of ``_MASK_GRIDS`` whose grid has ``cells`` cells."""
+    for stride, up in _MASK_GRIDS:
+        rows, cols = up * (height // stride), up * (width // stride)
+        if rows * cols == cells:
+            return stride // up, rows, cols
+    return None
+
+
 def get_bbox_from_patch_mask(patch_mask, init_image_size, img_np: Optional[np.ndarray] = None) -> np.ndarray:
     """Boolean patch mask (``eigenvectors[1] > 0``, any shape with ``T`` elements, tensor or array) + the padded image
     size ``(C, H, W)`` -> pixel box ``[xmin, ymin, xmax, ymax]`` (object_discovery.py:85-126): the mask grid is inferred
-    from ``T`` (patch 8, patch 16, or 16 upsampled 2x / 32 upsampled 4x, in the reference's order of preference), a mask
-    that covers more than half of the grid - or nothing - is inverted, and the box of its largest connected component
-    is scaled by the patch size and clipped to the image."""
-    H, W = init_image_size[1:]
-    patch_mask = patch_mask.cpu().numpy() if isinstance(patch_mask, torch.Tensor) else np.asarray(patch_mask)
-    T = patch_mask.size
-    if (H // 8) * (W // 8) == T:
-        P, H_lr, W_lr = 8, H // 8, W // 8
-    elif (H // 16) * (W // 16) == T:
-        P, H_lr, W_lr = 16, H // 16, W // 16
-    elif 4 * (H // 16) * (W // 16) == T:
-        P, H_lr, W_lr = 8, 2 * (H // 16), 2 * (W // 16)
-    elif 16 * (H // 32) * (W // 32) == T:
-        P, H_lr, W_lr = 8, 4 * (H // 32), 4 * (W // 32)
-    else:
+    from ``T`` (``_MASK_GRIDS``), a mask that covers more than half of the grid - or nothing - is inverted, and the box of
+    its largest connected component is scaled to pixels and clipped to the image.  A ``T`` that fits no grid raises the
+    reference's ``ValueError`` (same message)."""
+    height, width = (int(v) for v in init_image_size[1:])
+    mask = patch_mask.cpu().numpy() if isinstance(patch_mask, torch.Tensor) else np.asarray(patch_mask)
+    grid = _mask_grid(height, width, mask.size)
+    if grid is None:
         raise ValueError(f"{init_image_size=}, {patch_mask.shape=}")
-    patch_mask = patch_mask.reshape(H_lr, W_lr)
-    if 0.5 < np.mean(patch_mask).item() < 1.0 or np.sum(patch_mask).item() == 0:
-        patch_mask = (1 - patch_mask).astype(np.uint8)   # reversed segment / nothing detected: cover the complement
-    xmin, ymin, xmax, ymax = get_largest_cc_box(patch_mask)
-    return np.asarray([P * xmin, P * ymin, min(P * xmax, W), min(P * ymax, H)])
+    scale, rows, cols = grid
+    mask = mask.reshape(rows, cols)
+    covered = float(np.mean(mask))
+    if 0.5 < covered < 1.0 or not mask.any():
+        mask = (1 - mask).astype(np.uint8)      # reversed segment / nothing detected: box the complement
+    box = np.asarray(get_largest_cc_box(mask)) * scale
+    return np.minimum(box, [box[0], box[1], width, height])          # (a padded image: the box ends at the image)
 
 
 def bbox_iou(box1: torch.Tensor, box2: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
