@@ -260,6 +260,10 @@ class _FastSaver:
 
     def submit_features(self, slot: int, items: List[tuple], chunk: int = 8):
         path, _, _, nbytes = self.slots[slot]
+        try:
+            os.utime(path)                           # a live block must not look hours-old to another run's _sweep_stale
+        except OSError:
+            pass
         for s in range(0, len(items), chunk):
             self.pending[slot].append(self.pool.apply_async(pthfast.save_chunk, (path, nbytes, "features", items[s:s + chunk])))
 
