@@ -85,9 +85,10 @@ bool deterministic_solution(const std::string& name, size_t workspace) {
 // at D = 384 (N = 384, K = 1536) the 192 x 128 tile is 13.5 % faster than the 192 x 256 one the heuristic puts first at 2.2 M rows,
 // 6.4 % at 1.1 M, 6.5 % at 262 k, 3.2 % at 86 k - and returns the same bits (so do 194 of the 227 solutions that support the
 // problem).  In place, on real activations, it is worth 2.2 % of the fc2 site (same-box A/B, three rounds) - operand data move the
-// clock, and synthetic operands overstate the difference.  A preference is a tile shape looked for AMONG THE HEURISTIC'S OWN CANDIDATES, under the same no-workspace rule; where
-// no candidate has it (another build of the library) the walk takes the first qualifying candidate as before.  Shapes whose
-// fastest kernel changes with the row count (attn.proj at D = 768: -9 % at 1.05 M rows, +27 % at 262 k) have no entry.
+// clock, and synthetic operands overstate the difference.  A preference is a tile shape looked for AMONG THE HEURISTIC'S OWN
+// CANDIDATES, under the same no-workspace rule; where no candidate has it (another build of the library) the walk takes the first
+// qualifying candidate as before.  Shapes whose fastest kernel changes with the row count (attn.proj at D = 768: -9 % at 1.05 M
+// rows, +27 % at 262 k) have no entry.
 struct LtPreference { int N, K, dtype, out_dtype; long min_M; const char* tile; };
 constexpr LtPreference kPreferred[] = {
     {384, 1536, DSS_F16, DSS_F16, 65536, "_MT192x128x64_MI16x16x1_"},
