@@ -121,9 +121,11 @@ def parse():
                          "erf = the same function evaluated in fp32 (the A/B arm: +3.9 %% step time); "
                          "tanh_fused = hipBLASLt epilogue (tanh approximation, NOT the reference function; diagnostic only)")
     ap.add_argument("--vit-streams", type=int, default=1,
-                    help="run the ViT forwards of consecutive sub-batches on this many alternating streams (2: +1.7 %% "
-                         "measured - one forward's kernels fill the other's tails; default 1 because the per-kernel "
-                         "HIP-event durations behind `roofline` then overlap and read long)")
+                    help="run the ViT forwards of consecutive sub-batches on this many alternating streams (A/B arm.  2 measured "
+                         "+1.7 %% in round 2 - one forward's kernels filled the other's tails - and -11 %% with round 6's kernels "
+                         "(12 859 / 12 771 against 14 367 / 14 323 images/s, one box, alternating): the forwards are whole rounds "
+                         "of workgroups now and two of them only compete for the same CUs' LDS and HBM; the per-kernel "
+                         "HIP-event durations behind `roofline` also overlap and read long)")
     ap.add_argument("--shard-forwards", type=int, default=4,
                     help="a step that is not whole forwards of --vit-batch images (a rank's shard) is cut into at least this many forwards (chunk_counts)")
     ap.add_argument("--balanced-chunks", action="store_true",
